@@ -1,0 +1,192 @@
+/* amlike.h -- C ABI of the MI355X acoustic-likelihood engine (libamlike.so).
+ *
+ * Plain C: opaque handles, raw pointers + sizes + leading dimensions (in
+ * floats, what kaldi::MatrixBase::Stride() returns), int status codes.  No
+ * exception and no C++/torch type crosses this boundary.  The reference keeps
+ * the same shape of boundary under its own C++ matrix classes: extern "C"
+ * launchers taking raw device pointers and a {rows, cols, stride} struct
+ * (/root/reference/src/cudamatrix/cu-kernels-ansi.h:33-168,
+ *  /root/reference/src/cudamatrix/cu-matrixdim.h:47-88).
+ *
+ * All reference paths below are relative to /root/reference/src.
+ */
+#ifndef AMLIKE_H_
+#define AMLIKE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes.  The C++ shim layer rethrows them as std::runtime_error with
+ * the reference's message (base/kaldi-error.cc:173-185). */
+#define AMLIKE_OK 0
+#define AMLIKE_EINVAL 1     /* bad argument / handle */
+#define AMLIKE_EDIM 2       /* "Dim mismatch: data dim = .. vs. model dim = .."  gmm/decodable-am-diag-gmm.cc:49-52 */
+#define AMLIKE_ENONFINITE 3 /* "Invalid answer (overflow or invalid variances/features?)" gmm/diag-gmm.cc:523-524 */
+#define AMLIKE_EHIP 4       /* a HIP runtime call failed (CU_SAFE_CALL analogue, cudamatrix/cu-common.h:38-45) */
+#define AMLIKE_EOOM 5       /* device allocation failed (cudamatrix/cu-device.cc:640-652) */
+#define AMLIKE_ENODEV 6     /* no usable GPU (cudamatrix/cu-device.cc:99-138) */
+
+typedef struct amlike_gmm amlike_gmm_t;   /* packed AmDiagGmm resident in HBM */
+typedef struct amlike_nnet amlike_nnet_t; /* nnet2 forward pipeline resident in HBM */
+
+/* ---- device / process ---------------------------------------------------- */
+
+/* Replaces CuDevice::SelectGpuId (cudamatrix/cu-device.cc:64-138): binds the
+ * calling thread (and every handle created afterwards) to `device`.
+ * Returns AMLIKE_ENODEV when no gfx950 device is visible. */
+int amlike_init(int device);
+
+/* Last error text of the calling thread (KALDI_ERR message analogue). */
+const char *amlike_last_error(void);
+
+/* Number of visible devices (0 when there is none). */
+int amlike_device_count(void);
+
+/* ---- diagonal-GMM acoustic model ----------------------------------------- */
+
+/* Replaces the in-memory form of AmDiagGmm (gmm/am-diag-gmm.h:36-111: a vector
+ * of separately allocated DiagGmm, gmm/diag-gmm.h:231-237).  The caller passes
+ * the model flattened in pdf order:
+ *   gconsts[G], means_invvars[G x dim], inv_vars[G x dim]  (row-major, dense),
+ *   pdf_offsets[num_pdfs + 1]: pdf j owns Gaussians [pdf_offsets[j], pdf_offsets[j+1]).
+ * gconsts are the values DiagGmm::ComputeGconsts produces (gmm/diag-gmm.cc:114-152).
+ * Host arrays are only read during the call; the handle owns a re-packed device copy. */
+int amlike_gmm_create(const float *gconsts, const float *means_invvars,
+                      const float *inv_vars, const int32_t *pdf_offsets,
+                      int32_t num_pdfs, int32_t num_gauss, int32_t dim,
+                      amlike_gmm_t **out);
+int amlike_gmm_destroy(amlike_gmm_t *gmm);
+
+/* Replaces DiagGmm::ComputeGconsts (gmm/diag-gmm.cc:114-152) for num_gauss
+ * Gaussians given flat (host arithmetic, same precisions as the reference):
+ * gc = log w - 0.5 D log 2pi + sum_d (0.5 log iv - 0.5 miv^2 / iv); +inf -> -inf and
+ * counted in *num_bad (may be NULL); NaN -> AMLIKE_ENONFINITE
+ * ("not a number in gconst computation"). */
+int amlike_gmm_compute_gconsts(const float *weights, const float *means_invvars,
+                               const float *inv_vars, int32_t num_gauss, int32_t dim,
+                               float *gconsts, int32_t *num_bad);
+int32_t amlike_gmm_num_pdfs(const amlike_gmm_t *gmm);
+int32_t amlike_gmm_num_gauss(const amlike_gmm_t *gmm);
+int32_t amlike_gmm_dim(const amlike_gmm_t *gmm);
+
+/* Replaces the frame x pdf loop of gmm-compute-likes
+ * (gmmbin/gmm-compute-likes.cc:71-77 -> AmDiagGmm::LogLikelihood,
+ * gmm/am-diag-gmm.h:108-111 -> DiagGmm::LogLikelihood, gmm/diag-gmm.cc:517-526)
+ * and the per-(frame,pdf) body of DecodableAmDiagGmmUnmapped::LogLikelihoodZeroBased
+ * (gmm/decodable-am-diag-gmm.cc:28-72), computed densely:
+ *   out[t*ldo + j] = log sum_m exp(gconst_m + means_invvars_m . x_t - 0.5 inv_vars_m . x_t^2)
+ * feats: [T x dim] with row stride ld; out: [T x num_pdfs] with row stride ldo.
+ * log_sum_exp_prune <= 0: plain LogSumExp(); > 0: terms below max - prune are
+ * dropped (matrix/kaldi-vector.cc:766-784).
+ * Host-pointer form: copies in, computes, copies out, synchronises.
+ * Returns AMLIKE_ENONFINITE if any output is NaN/Inf (the output is still written). */
+int amlike_gmm_score(amlike_gmm_t *gmm, const float *feats, int32_t T, int32_t ld,
+                     int32_t feat_dim, float log_sum_exp_prune, float *out, int32_t ldo);
+
+/* Device-pointer form: feats/out are device memory, the work is enqueued on
+ * `stream` (a hipStream_t, or NULL for the default stream) and NOT waited for.
+ * The NaN/Inf flag of the most recent launch is read with amlike_gmm_poll(). */
+int amlike_gmm_score_dev(amlike_gmm_t *gmm, const float *d_feats, int32_t T, int32_t ld,
+                         int32_t feat_dim, float log_sum_exp_prune, float *d_out,
+                         int32_t ldo, void *stream);
+
+/* Waits for `stream` and returns AMLIKE_OK or AMLIKE_ENONFINITE for the
+ * launches since the previous poll. */
+int amlike_gmm_poll(amlike_gmm_t *gmm, void *stream);
+
+/* Replaces DiagGmm::LogLikelihoods(Matrix) (gmm/diag-gmm.cc:546-562) and, row by
+ * row, DiagGmm::LogLikelihoods(Vector) (:528-543): per-Gaussian scores
+ *   out[t*ldo + g] = gconst_g + means_invvars_g . x_t - 0.5 inv_vars_g . x_t^2
+ * for Gaussians g in [pdf_offsets[pdf_begin], pdf_offsets[pdf_end]) of the packed
+ * model (a single DiagGmm is the case num_pdfs == 1).  Host pointers. */
+int amlike_gmm_gauss_loglikes(amlike_gmm_t *gmm, int32_t pdf_begin, int32_t pdf_end,
+                              const float *feats, int32_t T, int32_t ld, int32_t feat_dim,
+                              float *out, int32_t ldo);
+int amlike_gmm_gauss_loglikes_dev(amlike_gmm_t *gmm, int32_t pdf_begin, int32_t pdf_end,
+                                  const float *d_feats, int32_t T, int32_t ld,
+                                  int32_t feat_dim, float *d_out, int32_t ldo, void *stream);
+
+/* Name and grid of the kernels the last score launch used (for profiling output). */
+const char *amlike_gmm_kernel_info(const amlike_gmm_t *gmm);
+
+/* Timing hook: runs `iters` back-to-back launches of the scoring kernel on
+ * `stream`, bracketed by hipEvents on that stream, and returns the mean kernel
+ * time in milliseconds in *ms_per_launch (CuDevice::AccuProfile analogue,
+ * cudamatrix/cu-device.h:84-92). */
+int amlike_gmm_time_score_dev(amlike_gmm_t *gmm, const float *d_feats, int32_t T, int32_t ld,
+                              int32_t feat_dim, float *d_out, int32_t ldo, void *stream,
+                              int32_t iters, float *ms_per_launch);
+
+/* ---- nnet2 forward -------------------------------------------------------- */
+
+/* Component kinds of the p-norm nnet2 forward path
+ * (nnet2/nnet-component.cc: Splice :2411-2471, FixedAffine :3028-3034,
+ * Affine / AffineComponentPreconditioned(Online) :1123-1131, Pnorm :530-535,
+ * Normalize :578-592, Softmax :905-918, SumGroup :2352-2357, and the
+ * elementwise Sigmoid :639, Tanh :673, RectifiedLinear :782). */
+enum amlike_component_kind {
+  AMLIKE_SPLICE = 1,
+  AMLIKE_AFFINE = 2, /* also FixedAffine: out = in * W^T + b, W is [out_dim x in_dim] */
+  AMLIKE_PNORM = 3,
+  AMLIKE_NORMALIZE = 4,
+  AMLIKE_SOFTMAX = 5,
+  AMLIKE_SUMGROUP = 6,
+  AMLIKE_SIGMOID = 7,
+  AMLIKE_TANH = 8,
+  AMLIKE_RELU = 9
+};
+
+typedef struct amlike_component {
+  int32_t kind;          /* enum amlike_component_kind */
+  int32_t input_dim;
+  int32_t output_dim;
+  int32_t left_context;  /* SPLICE */
+  int32_t right_context; /* SPLICE */
+  int32_t const_dim;     /* SPLICE: const_component_dim_ */
+  float p;               /* PNORM */
+  const float *linear;   /* AFFINE: [output_dim x input_dim] row-major, dense */
+  const float *bias;     /* AFFINE: [output_dim] */
+  const int32_t *sizes;  /* SUMGROUP: [output_dim] group sizes */
+} amlike_component_t;
+
+/* Replaces Nnet (nnet2/nnet-nnet.h:62-) + AmNnet::Priors (nnet2/am-nnet.h) as a
+ * device-resident forward pipeline.  priors may be NULL (then num_priors = 0). */
+int amlike_nnet_create(const amlike_component_t *components, int32_t num_components,
+                       const float *priors, int32_t num_priors, amlike_nnet_t **out);
+int amlike_nnet_destroy(amlike_nnet_t *nnet);
+int32_t amlike_nnet_input_dim(const amlike_nnet_t *nnet);
+int32_t amlike_nnet_output_dim(const amlike_nnet_t *nnet);
+int32_t amlike_nnet_left_context(const amlike_nnet_t *nnet);  /* Nnet::LeftContext nnet2/nnet-nnet.cc:39-45 */
+int32_t amlike_nnet_right_context(const amlike_nnet_t *nnet); /* Nnet::RightContext :47-53 */
+
+/* Output post-processing of amlike_nnet_compute. */
+#define AMLIKE_NNET_POSTERIORS 0 /* NnetComputation output as is (nnet2/nnet-compute.cc:158-165) */
+#define AMLIKE_NNET_LOG 1        /* + ApplyFloor(1e-20), ApplyLog (nnet2bin/nnet-am-compute.cc:93-96) */
+#define AMLIKE_NNET_LOGLIKES 2   /* + minus log prior, times prob_scale (nnet2/decodable-am-nnet.h:59-69) */
+
+/* Replaces NnetComputation(nnet, feats, pad_input, &out) (nnet2/nnet-compute.h:44-47,
+ * nnet2/nnet-compute.cc:62-106,158-165).  feats [T x input_dim] stride ld;
+ * out [T_out x output_dim] stride ldo with T_out = T if pad_input else
+ * T - left_context - right_context.  Host pointers, synchronous. */
+int amlike_nnet_compute(amlike_nnet_t *nnet, const float *feats, int32_t T, int32_t ld,
+                        int32_t pad_input, int32_t mode, float prob_scale, float *out,
+                        int32_t ldo);
+/* Device-pointer, asynchronous form. */
+int amlike_nnet_compute_dev(amlike_nnet_t *nnet, const float *d_feats, int32_t T, int32_t ld,
+                            int32_t pad_input, int32_t mode, float prob_scale, float *d_out,
+                            int32_t ldo, void *stream);
+
+/* Per-kernel timing of the last amlike_nnet_compute* call pattern: runs `iters`
+ * forward passes and returns mean milliseconds per pass. */
+int amlike_nnet_time_compute_dev(amlike_nnet_t *nnet, const float *d_feats, int32_t T,
+                                 int32_t ld, int32_t pad_input, int32_t mode, float prob_scale,
+                                 float *d_out, int32_t ldo, void *stream, int32_t iters,
+                                 float *ms_per_pass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMLIKE_H_ */

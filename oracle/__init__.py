@@ -1,0 +1,202 @@
+"""oracle/ -- TEST INFRASTRUCTURE ONLY (the checker, never the product).
+
+``load()`` gives ctypes access to the plain-C CPU restatement of the reference's
+acoustic-likelihood path (gmm_oracle.c, nnet_oracle.c -> liboracle.so);
+``ref_driver()`` runs the real reference library built by build_ref.sh
+(oracle/_ref/ref_driver), when it is present.
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg may
+import this package.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_double, c_float, c_int, c_int32
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+REF_DRIVER = os.path.join(HERE, "_ref", "ref_driver")
+SOURCES = ["gmm_oracle.c", "nnet_oracle.c"]
+
+_lib = None
+
+
+def build(force=False):
+    """gcc -O2 (the reference's optimisation level, makefiles/linux_clapack.mk) -> liboracle.so."""
+    srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    if not force and os.path.exists(LIB) and all(
+            os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
+        return LIB
+    subprocess.check_call(["gcc", "-O2", "-msse", "-msse2", "-fPIC", "-shared", "-std=c99",
+                           "-D_POSIX_C_SOURCE=200809L", "-o", LIB] + srcs + ["-lm"])
+    return LIB
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = ctypes.CDLL(LIB)
+        fp, ip = POINTER(c_float), POINTER(c_int32)
+        L.oracle_compute_gconsts.restype = c_int
+        L.oracle_compute_gconsts.argtypes = [fp, fp, fp, c_int, c_int, fp]
+        L.oracle_log_sum_exp.restype = c_float
+        L.oracle_log_sum_exp.argtypes = [fp, c_int, c_float]
+        L.oracle_gmm_compute_likes.restype = c_int
+        L.oracle_gmm_compute_likes.argtypes = [fp, fp, fp, ip, c_int, c_int, fp, c_int, c_int,
+                                               c_float, fp, c_int, fp]
+        L.oracle_diag_gmm_loglikes_mat.restype = None
+        L.oracle_diag_gmm_loglikes_mat.argtypes = [fp, fp, fp, c_int, c_int, fp, c_int, c_int, fp,
+                                                   c_int, fp]
+        L.oracle_now.restype = c_double
+        if hasattr(L, "oracle_nnet_compute"):
+            _declare_nnet(L)
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(POINTER(c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(POINTER(c_int32))
+
+
+def compute_gconsts(weights, miv, iv):
+    L = load()
+    w = np.ascontiguousarray(weights, np.float32)
+    miv = np.ascontiguousarray(miv, np.float32)
+    iv = np.ascontiguousarray(iv, np.float32)
+    G, D = miv.shape
+    gc = np.empty(G, np.float32)
+    bad = L.oracle_compute_gconsts(_fp(w), _fp(miv), _fp(iv), G, D, _fp(gc))
+    return gc, bad
+
+
+def gmm_compute_likes(gconsts, miv, iv, offsets, feats, prune=-1.0):
+    """Returns (loglikes[T x P], status)."""
+    L = load()
+    gconsts = np.ascontiguousarray(gconsts, np.float32)
+    miv = np.ascontiguousarray(miv, np.float32)
+    iv = np.ascontiguousarray(iv, np.float32)
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    feats = np.ascontiguousarray(feats, np.float32)
+    T, D = feats.shape
+    P = len(offsets) - 1
+    out = np.empty((T, P), np.float32)
+    scratch = np.empty(int(np.diff(offsets).max()) + D, np.float32)
+    st = L.oracle_gmm_compute_likes(_fp(gconsts), _fp(miv), _fp(iv), _ip(offsets), P, D,
+                                    _fp(feats), T, D, float(prune), _fp(out), P, _fp(scratch))
+    return out, st
+
+
+def diag_gmm_loglikes_mat(gconsts, miv, iv, feats):
+    L = load()
+    gconsts = np.ascontiguousarray(gconsts, np.float32)
+    miv = np.ascontiguousarray(miv, np.float32)
+    iv = np.ascontiguousarray(iv, np.float32)
+    feats = np.ascontiguousarray(feats, np.float32)
+    T, D = feats.shape
+    M = miv.shape[0]
+    out = np.empty((T, M), np.float32)
+    scratch = np.empty(D, np.float32)
+    L.oracle_diag_gmm_loglikes_mat(_fp(gconsts), _fp(miv), _fp(iv), M, D, _fp(feats), T, D,
+                                   _fp(out), M, _fp(scratch))
+    return out
+
+
+# ------------------------------------------------------------------- nnet2
+class NnetLayer(ctypes.Structure):
+    _fields_ = [("kind", c_int32), ("input_dim", c_int32), ("output_dim", c_int32),
+                ("left_context", c_int32), ("right_context", c_int32), ("const_dim", c_int32),
+                ("p", c_float), ("linear", POINTER(c_float)), ("bias", POINTER(c_float)),
+                ("sizes", POINTER(c_int32))]
+
+
+def _declare_nnet(L):
+    fp = POINTER(c_float)
+    L.oracle_nnet_compute.restype = c_int
+    L.oracle_nnet_compute.argtypes = [POINTER(NnetLayer), c_int, fp, c_int, fp, c_int, c_int,
+                                      c_int, c_int, c_float, fp, c_int]
+    L.oracle_nnet_context.restype = None
+    L.oracle_nnet_context.argtypes = [POINTER(NnetLayer), c_int, POINTER(c_int), POINTER(c_int)]
+
+
+KINDS = {"SpliceComponent": 1, "FixedAffineComponent": 2, "AffineComponent": 2,
+         "AffineComponentPreconditioned": 2, "AffineComponentPreconditionedOnline": 2,
+         "PnormComponent": 3, "NormalizeComponent": 4, "SoftmaxComponent": 5,
+         "SumGroupComponent": 6, "SigmoidComponent": 7, "TanhComponent": 8,
+         "RectifiedLinearComponent": 9}
+
+
+def make_layers(components, struct=NnetLayer):
+    """dict components (kaldi_io.write_component form) -> (ctypes array, keepalive list)."""
+    arr = (struct * len(components))()
+    keep = []
+    for k, c in enumerate(components):
+        t = c["type"]
+        a = arr[k]
+        a.kind = KINDS[t]
+        if t == "SpliceComponent":
+            a.input_dim = c["input_dim"]
+            a.left_context, a.right_context = c["left"], c["right"]
+            a.const_dim = c.get("const_dim", 0)
+            a.output_dim = (c["input_dim"] - a.const_dim) * (c["left"] + 1 + c["right"]) + a.const_dim
+        elif a.kind == 2:
+            W = np.ascontiguousarray(c["linear"], np.float32)
+            b = np.ascontiguousarray(c["bias"], np.float32)
+            keep += [W, b]
+            a.output_dim, a.input_dim = W.shape
+            a.linear, a.bias = _fp(W), _fp(b)
+        elif t == "PnormComponent":
+            a.input_dim, a.output_dim, a.p = c["input_dim"], c["output_dim"], c.get("p", 2.0)
+        elif t == "SumGroupComponent":
+            s = np.ascontiguousarray(c["sizes"], np.int32)
+            keep.append(s)
+            a.sizes = _ip(s)
+            a.input_dim, a.output_dim = int(s.sum()), len(s)
+        else:
+            a.input_dim = a.output_dim = c["dim"]
+    return arr, keep
+
+
+def nnet_compute(components, priors, feats, pad_input=True, mode=0, prob_scale=1.0):
+    """mode 0: posteriors, 1: +floor+log, 2: pseudo log-likelihoods. Returns [T_out x P]."""
+    L = load()
+    arr, keep = make_layers(components)
+    feats = np.ascontiguousarray(feats, np.float32)
+    T, D = feats.shape
+    left, right = c_int(0), c_int(0)
+    L.oracle_nnet_context(arr, len(components), ctypes.byref(left), ctypes.byref(right))
+    t_out = T if pad_input else T - left.value - right.value
+    out_dim = arr[len(components) - 1].output_dim
+    out = np.empty((t_out, out_dim), np.float32)
+    pri = np.ascontiguousarray(priors if priors is not None else np.zeros(0), np.float32)
+    st = L.oracle_nnet_compute(arr, len(components), _fp(pri), len(pri), _fp(feats), T, D,
+                               1 if pad_input else 0, mode, float(prob_scale), _fp(out), out_dim)
+    if st != 0:
+        raise RuntimeError("oracle_nnet_compute status %d" % st)
+    return out
+
+
+# ------------------------------------------------------------- real reference
+def have_ref():
+    return os.path.exists(REF_DRIVER) and os.access(REF_DRIVER, os.X_OK)
+
+
+def ref_driver(*args, timeout=3600):
+    """Runs oracle/_ref/ref_driver (the real reference library). Returns stdout."""
+    env = dict(os.environ)
+    env["MKL_THREADING_LAYER"] = "SEQUENTIAL"
+    env["MKL_NUM_THREADS"] = "1"
+    env["OMP_NUM_THREADS"] = "1"
+    env["LD_LIBRARY_PATH"] = os.path.join(HERE, "_ref", "mkl")
+    p = subprocess.run([REF_DRIVER] + [str(a) for a in args], env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    if p.returncode != 0:
+        raise RuntimeError("ref_driver %s failed (%d): %s" % (args[0], p.returncode, p.stderr[-2000:]))
+    return p.stdout

@@ -1,0 +1,472 @@
+"""oracle/kaldi_io.py -- TEST INFRASTRUCTURE ONLY.
+
+A numpy restatement of the reference's on-disk formats for the objects on the
+acoustic-likelihood path, used by tests to generate model / feature files and
+to read back what the product and the reference driver write.  The product's
+own readers and writers are C++ (kaldi_amd/csrc/host/); nothing here is
+imported by the product.
+
+Pinned: tests/test_oracle_vs_ref.py round-trips every writer here through the
+real reference library's Read/Write (oracle/_ref/ref_driver *-copy), except the
+TransitionModel/Topology writer, which the reference build cannot cover
+(hmm/transition-model.h needs an OpenFst header the image lacks): that one is
+"parity unpinned" and follows hmm/transition-model.cc:296-318 and
+hmm/hmm-topology.cc:142-194 by reading.
+
+Format sources (paths relative to /root/reference/src):
+  tokens            base/io-funcs.cc:130-164        "tok" + one space, text and binary
+  ints              base/io-funcs-inl.h:32-88       binary: int8 sizeof, then LE bytes
+  float/double      base/io-funcs.cc:51-127         binary: int8 4|8, then raw bytes
+  bool              base/io-funcs.cc:26-48          'T' / 'F'
+  int vectors       base/io-funcs-inl.h:91-179
+  binary marker     base/io-funcs-inl.h:183-215     "\\0B"
+  Vector            matrix/kaldi-vector.cc:1224-1244 (write), :1107-1222 (read)
+  Matrix            matrix/kaldi-matrix.cc:1118-1157 (write), :1160-1352 (read)
+  ark               util/kaldi-holder-inl.h:45-84   "key " + ["\\0B"] + object
+"""
+import io
+import struct
+
+import numpy as np
+
+
+# ----------------------------------------------------------------- primitives
+def write_token(f, binary, tok):
+    f.write(tok.encode() + b" ")
+
+
+def write_int32(f, binary, v):
+    if binary:
+        f.write(struct.pack("<bi", 4, int(v)))
+    else:
+        f.write(b"%d " % int(v))
+
+
+def write_float(f, binary, v):
+    if binary:
+        f.write(struct.pack("<bf", 4, float(v)))
+    else:
+        f.write(("%.9g " % float(np.float32(v))).encode())
+
+
+def write_double(f, binary, v):
+    if binary:
+        f.write(struct.pack("<bd", 8, float(v)))
+    else:
+        f.write(("%.17g " % float(v)).encode())
+
+
+def write_bool(f, binary, v):
+    f.write(b"T" if v else b"F")
+    if not binary:
+        f.write(b" ")
+
+
+def write_int_vector(f, binary, v):
+    v = np.asarray(v, dtype=np.int32)
+    if binary:
+        f.write(struct.pack("<bi", 4, v.size))
+        f.write(v.astype("<i4").tobytes())
+    else:
+        f.write(b"[ " + b"".join(b"%d " % int(x) for x in v) + b"]\n")
+
+
+def _fmt(x, double):
+    x = float(x)
+    if np.isinf(x):
+        return "inf" if x > 0 else "-inf"
+    if np.isnan(x):
+        return "nan"
+    return ("%.17g" if double else "%.9g") % x
+
+
+def write_vector(f, binary, v, double=False):
+    v = np.asarray(v, dtype=np.float64 if double else np.float32)
+    if binary:
+        write_token(f, binary, "DV" if double else "FV")
+        write_int32(f, binary, v.size)
+        f.write(v.astype("<f8" if double else "<f4").tobytes())
+    else:
+        f.write((" [ " + "".join(_fmt(x, double) + " " for x in v) + "]\n").encode())
+
+
+def write_matrix(f, binary, m, double=False):
+    m = np.asarray(m, dtype=np.float64 if double else np.float32)
+    assert m.ndim == 2
+    if binary:
+        write_token(f, binary, "DM" if double else "FM")
+        write_int32(f, binary, m.shape[0])
+        write_int32(f, binary, m.shape[1])
+        f.write(np.ascontiguousarray(m).astype("<f8" if double else "<f4").tobytes())
+    else:
+        if m.shape[0] == 0:
+            f.write(b" [ ]\n")
+            return
+        out = [" ["]
+        for r in range(m.shape[0]):
+            out.append("\n  " + "".join(_fmt(x, double) + " " for x in m[r]))
+        out.append("]\n")
+        f.write("".join(out).encode())
+
+
+# -------------------------------------------------------------------- readers
+class Reader:
+    """Minimal token/number reader over a bytes buffer (binary or text mode)."""
+
+    def __init__(self, data, pos=0):
+        self.d = data
+        self.p = pos
+
+    def peek(self):
+        return self.d[self.p:self.p + 1]
+
+    def eof(self):
+        return self.p >= len(self.d)
+
+    def read_binary_marker(self):
+        if self.d[self.p:self.p + 2] == b"\0B":
+            self.p += 2
+            return True
+        return False
+
+    def skip_ws(self):
+        while self.p < len(self.d) and self.d[self.p:self.p + 1] in b" \t\r\n":
+            self.p += 1
+
+    def token(self):
+        self.skip_ws()
+        s = self.p
+        while self.p < len(self.d) and self.d[self.p:self.p + 1] not in b" \t\r\n":
+            self.p += 1
+        tok = self.d[s:self.p].decode()
+        self.p += 1  # the single separator
+        return tok
+
+    def expect(self, tok):
+        t = self.token()
+        if t != tok:
+            raise ValueError("expected %s got %s" % (tok, t))
+
+    def int32(self, binary):
+        if binary:
+            sz, v = struct.unpack_from("<bi", self.d, self.p)
+            assert sz == 4
+            self.p += 5
+            return v
+        return int(self.token())
+
+    def float32(self, binary):
+        if binary:
+            sz = struct.unpack_from("<b", self.d, self.p)[0]
+            if sz == 4:
+                v = struct.unpack_from("<f", self.d, self.p + 1)[0]
+            else:
+                assert sz == 8
+                v = struct.unpack_from("<d", self.d, self.p + 1)[0]
+            self.p += 1 + sz
+            return v
+        return float(self.token())
+
+    def vector(self, binary):
+        if binary:
+            tok = self.token()
+            dt = {"FV": "<f4", "DV": "<f8"}[tok]
+            n = self.int32(True)
+            a = np.frombuffer(self.d, dtype=dt, count=n, offset=self.p)
+            self.p += a.nbytes
+            return a.astype(np.float32 if tok == "FV" else np.float64)
+        self.expect("[")
+        vals = []
+        while True:
+            t = self.token()
+            if t == "]":
+                break
+            vals.append(float(t))
+        return np.array(vals, dtype=np.float32)
+
+    def matrix(self, binary):
+        if binary:
+            tok = self.token()
+            dt = {"FM": "<f4", "DM": "<f8"}[tok]
+            r = self.int32(True)
+            c = self.int32(True)
+            a = np.frombuffer(self.d, dtype=dt, count=r * c, offset=self.p)
+            self.p += a.nbytes
+            return a.reshape(r, c).astype(np.float32)
+        self.expect("[")
+        rows, cur = [], []
+        while True:
+            # rows end at a newline or ';' (matrix/kaldi-matrix.cc:1268-1337)
+            self.skip_spaces_only()
+            ch = self.peek()
+            if ch in (b"\n", b";"):
+                self.p += 1
+                if cur:
+                    rows.append(cur)
+                    cur = []
+                continue
+            t = self.token_nonl()
+            if t == "]":
+                if cur:
+                    rows.append(cur)
+                break
+            cur.append(float(t))
+        if not rows:
+            return np.zeros((0, 0), dtype=np.float32)
+        return np.array(rows, dtype=np.float32)
+
+    def skip_spaces_only(self):
+        while self.p < len(self.d) and self.d[self.p:self.p + 1] in b" \t\r":
+            self.p += 1
+
+    def token_nonl(self):
+        s = self.p
+        while self.p < len(self.d) and self.d[self.p:self.p + 1] not in b" \t\r\n;":
+            self.p += 1
+        return self.d[s:self.p].decode()
+
+
+def read_ark(path_or_bytes):
+    """Read a Matrix<float> archive (binary or text entries). Returns [(key, ndarray)]."""
+    data = path_or_bytes if isinstance(path_or_bytes, bytes) else open(path_or_bytes, "rb").read()
+    r = Reader(data)
+    out = []
+    while True:
+        r.skip_ws()
+        if r.eof():
+            break
+        key = r.token()
+        binary = r.read_binary_marker()
+        out.append((key, r.matrix(binary)))
+    return out
+
+
+def write_ark(path, items, binary=True):
+    with open(path, "wb") as f:
+        for key, m in items:
+            f.write(key.encode() + b" ")
+            if binary:
+                f.write(b"\0B")
+            write_matrix(f, binary, m)
+
+
+def read_vector_file(path):
+    r = Reader(open(path, "rb").read())
+    return r.vector(r.read_binary_marker())
+
+
+# ------------------------------------------------------------------ GMM model
+def write_diag_gmm(f, binary, weights, means_invvars, inv_vars, gconsts=None,
+                   old_tokens=False):
+    """gmm/diag-gmm.cc:705-720.  <GCONSTS> is optional on read (:736-743)."""
+    write_token(f, binary, "<DiagGMMBegin>" if old_tokens else "<DiagGMM>")
+    if not binary:
+        f.write(b"\n")
+    if gconsts is not None:
+        write_token(f, binary, "<GCONSTS>")
+        write_vector(f, binary, gconsts)
+    write_token(f, binary, "<WEIGHTS>")
+    write_vector(f, binary, weights)
+    write_token(f, binary, "<MEANS_INVVARS>")
+    write_matrix(f, binary, means_invvars)
+    write_token(f, binary, "<INV_VARS>")
+    write_matrix(f, binary, inv_vars)
+    write_token(f, binary, "<DiagGMMEnd>" if old_tokens else "</DiagGMM>")
+    if not binary:
+        f.write(b"\n")
+
+
+def write_am_diag_gmm(f, binary, dim, pdfs, with_gconsts=True):
+    """gmm/am-diag-gmm.cc:163-176.  pdfs: list of dicts(weights, means_invvars, inv_vars[, gconsts])."""
+    write_token(f, binary, "<DIMENSION>")
+    write_int32(f, binary, dim)
+    write_token(f, binary, "<NUMPDFS>")
+    write_int32(f, binary, len(pdfs))
+    for p in pdfs:
+        gc = p.get("gconsts") if with_gconsts else None
+        write_diag_gmm(f, binary, p["weights"], p["means_invvars"], p["inv_vars"], gc)
+
+
+def simple_topology(phones, num_states=3):
+    """A left-to-right topology for `phones` (self-loop 0.75, forward 0.25) as
+    (phones, phone2idx, entries) -- the members hmm/hmm-topology.cc:177-190 writes."""
+    phones = sorted(phones)
+    phone2idx = [-1] * (max(phones) + 1)
+    for p in phones:
+        phone2idx[p] = 0
+    entry = []
+    for s in range(num_states):
+        entry.append((s, [(s, 0.75), (s + 1, 0.25)]))
+    entry.append((-1, []))  # final non-emitting state
+    return phones, phone2idx, [entry]
+
+
+def write_topology(f, binary, topo):
+    """hmm/hmm-topology.cc:142-194."""
+    phones, phone2idx, entries = topo
+    write_token(f, binary, "<Topology>")
+    if not binary:
+        f.write(b"\n")
+        for i, entry in enumerate(entries):
+            f.write(b"<TopologyEntry> \n<ForPhones> \n")
+            f.write(b"".join(b"%d " % j for j in range(len(phone2idx)) if phone2idx[j] == i))
+            f.write(b"\n</ForPhones> \n")
+            for j, (pdf_class, trans) in enumerate(entry):
+                f.write(b"<State> %d " % j)
+                if pdf_class != -1:
+                    f.write(b"<PdfClass> %d " % pdf_class)
+                for dst, prob in trans:
+                    f.write(b"<Transition> %d " % dst)
+                    write_float(f, False, prob)
+                f.write(b"</State> \n")
+            f.write(b"</TopologyEntry> \n")
+    else:
+        write_int_vector(f, True, phones)
+        write_int_vector(f, True, phone2idx)
+        write_int32(f, True, len(entries))
+        for entry in entries:
+            write_int32(f, True, len(entry))
+            for pdf_class, trans in entry:
+                write_int32(f, True, pdf_class)
+                write_int32(f, True, len(trans))
+                for dst, prob in trans:
+                    write_int32(f, True, dst)
+                    write_float(f, True, prob)
+    write_token(f, binary, "</Topology>")
+    if not binary:
+        f.write(b"\n")
+
+
+def write_transition_model(f, binary, topo, triples):
+    """hmm/transition-model.cc:296-318.  triples: sorted list of (phone, hmm_state, pdf).
+    Returns tid2pdf (index 0 unused) as defined by ComputeDerived (:72-97)."""
+    phones, phone2idx, entries = topo
+    write_token(f, binary, "<TransitionModel>")
+    if not binary:
+        f.write(b"\n")
+    write_topology(f, binary, topo)
+    write_token(f, binary, "<Triples>")
+    write_int32(f, binary, len(triples))
+    if not binary:
+        f.write(b"\n")
+    tid2pdf = [-1]
+    log_probs = [0.0]
+    for (phone, hs, pdf) in triples:
+        write_int32(f, binary, phone)
+        write_int32(f, binary, hs)
+        write_int32(f, binary, pdf)
+        if not binary:
+            f.write(b"\n")
+        trans = entries[phone2idx[phone]][hs][1]
+        for (_, prob) in trans:
+            tid2pdf.append(pdf)
+            log_probs.append(np.log(prob))
+    write_token(f, binary, "</Triples>")
+    if not binary:
+        f.write(b"\n")
+    write_token(f, binary, "<LogProbs>")
+    if not binary:
+        f.write(b"\n")
+    write_vector(f, binary, np.array(log_probs, dtype=np.float32))
+    write_token(f, binary, "</LogProbs>")
+    if not binary:
+        f.write(b"\n")
+    write_token(f, binary, "</TransitionModel>")
+    if not binary:
+        f.write(b"\n")
+    return np.array(tid2pdf, dtype=np.int32)
+
+
+def make_transition_model(num_pdfs, states_per_phone=3):
+    """Synthetic (topology, triples) covering pdfs 0..num_pdfs-1: phone k (1-based)
+    has states 0..S-1 mapped to consecutive pdfs."""
+    nph = (num_pdfs + states_per_phone - 1) // states_per_phone
+    topo = simple_topology(list(range(1, nph + 1)), states_per_phone)
+    triples = []
+    for ph in range(1, nph + 1):
+        for s in range(states_per_phone):
+            pdf = min((ph - 1) * states_per_phone + s, num_pdfs - 1)
+            triples.append((ph, s, pdf))
+    triples = sorted(set(triples))
+    return topo, triples
+
+
+# ----------------------------------------------------------------- nnet2 model
+def write_component(f, binary, comp):
+    """nnet2/nnet-component.cc Write() of each type; comp is a dict with 'type'."""
+    t = comp["type"]
+    write_token(f, binary, "<%s>" % t)
+    if t == "SpliceComponent":  # :2579-2590
+        write_token(f, binary, "<InputDim>"); write_int32(f, binary, comp["input_dim"])
+        write_token(f, binary, "<LeftContext>"); write_int32(f, binary, comp["left"])
+        write_token(f, binary, "<RightContext>"); write_int32(f, binary, comp["right"])
+        write_token(f, binary, "<ConstComponentDim>"); write_int32(f, binary, comp.get("const_dim", 0))
+        write_token(f, binary, "</%s>" % t)
+    elif t == "FixedAffineComponent":  # :3054-3061
+        write_token(f, binary, "<LinearParams>"); write_matrix(f, binary, comp["linear"])
+        write_token(f, binary, "<BiasParams>"); write_vector(f, binary, comp["bias"])
+        write_token(f, binary, "</%s>" % t)
+    elif t == "AffineComponent":  # :1194-1208
+        write_token(f, binary, "<LearningRate>"); write_float(f, binary, comp.get("lr", 0.01))
+        write_token(f, binary, "<LinearParams>"); write_matrix(f, binary, comp["linear"])
+        write_token(f, binary, "<BiasParams>"); write_vector(f, binary, comp["bias"])
+        write_token(f, binary, "<IsGradient>"); write_bool(f, binary, False)
+        write_token(f, binary, "</%s>" % t)
+    elif t == "AffineComponentPreconditionedOnline":  # :1705-1729
+        write_token(f, binary, "<LearningRate>"); write_float(f, binary, comp.get("lr", 0.01))
+        write_token(f, binary, "<LinearParams>"); write_matrix(f, binary, comp["linear"])
+        write_token(f, binary, "<BiasParams>"); write_vector(f, binary, comp["bias"])
+        write_token(f, binary, "<RankIn>"); write_int32(f, binary, 20)
+        write_token(f, binary, "<RankOut>"); write_int32(f, binary, 80)
+        write_token(f, binary, "<UpdatePeriod>"); write_int32(f, binary, 4)
+        write_token(f, binary, "<NumSamplesHistory>"); write_float(f, binary, 2000.0)
+        write_token(f, binary, "<Alpha>"); write_float(f, binary, 4.0)
+        write_token(f, binary, "<MaxChangePerSample>"); write_float(f, binary, 0.075)
+        write_token(f, binary, "</%s>" % t)
+    elif t == "PnormComponent":  # :558-567
+        write_token(f, binary, "<InputDim>"); write_int32(f, binary, comp["input_dim"])
+        write_token(f, binary, "<OutputDim>"); write_int32(f, binary, comp["output_dim"])
+        write_token(f, binary, "<P>"); write_float(f, binary, comp.get("p", 2.0))
+        write_token(f, binary, "</%s>" % t)
+    elif t in ("NormalizeComponent", "SoftmaxComponent", "SigmoidComponent", "TanhComponent",
+               "RectifiedLinearComponent"):  # NonlinearComponent :390-404
+        write_token(f, binary, "<Dim>"); write_int32(f, binary, comp["dim"])
+        write_token(f, binary, "<ValueSum>"); write_vector(f, binary, np.zeros(0), double=True)
+        write_token(f, binary, "<DerivSum>"); write_vector(f, binary, np.zeros(0), double=True)
+        write_token(f, binary, "<Count>"); write_double(f, binary, 0.0)
+        write_token(f, binary, "</%s>" % t)
+    elif t == "SumGroupComponent":  # :2343-2350 (closing token has no slash)
+        write_token(f, binary, "<Sizes>"); write_int_vector(f, binary, comp["sizes"])
+        write_token(f, binary, "<SumGroupComponent>")
+    else:
+        raise ValueError(t)
+
+
+def write_am_nnet(f, binary, components, priors):
+    """nnet2/nnet-nnet.cc:74-87 then nnet2/am-nnet.cc:31-37."""
+    write_token(f, binary, "<Nnet>")
+    write_token(f, binary, "<NumComponents>")
+    write_int32(f, binary, len(components))
+    write_token(f, binary, "<Components>")
+    for c in components:
+        write_component(f, binary, c)
+        if not binary:
+            f.write(b"\n")
+    write_token(f, binary, "</Components>")
+    write_token(f, binary, "</Nnet>")
+    write_vector(f, binary, priors)
+
+
+def open_out(path, binary):
+    f = open(path, "wb")
+    if binary:
+        f.write(b"\0B")
+    return f
+
+
+def to_bytes(writer, binary, *args, **kw):
+    b = io.BytesIO()
+    if binary:
+        b.write(b"\0B")
+    writer(b, binary, *args, **kw)
+    return b.getvalue()

@@ -1,0 +1,148 @@
+"""GPU parity of the GMM scoring path: libamlike (HIP, through the C ABI) against
+the CPU oracle on the same seeded inputs.  Tolerance: 1e-3 absolute per
+(frame, pdf) log-likelihood and identical per-frame argmax pdf (the bar the
+benchmark definition states); observed differences are ~1e-5 (fp32 summation order)."""
+import numpy as np
+import pytest
+
+import oracle
+from kaldi_amd import _lib, gmm, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _check(m, feats, got, tol=TOL):
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    want, st = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"], feats)
+    assert st == 0
+    assert got.shape == want.shape
+    assert np.isfinite(got).all()
+    err = np.abs(got - want).max()
+    assert err < tol, "max abs diff %g" % err
+    # argmax agreement, allowing exact ties within the tolerance
+    am_got, am_want = got.argmax(1), want.argmax(1)
+    bad = am_got != am_want
+    if bad.any():
+        rows = np.nonzero(bad)[0]
+        gap = want[rows, am_want[rows]] - want[rows, am_got[rows]]
+        assert (gap < 1e-4).all(), "argmax differs on %d frames" % bad.sum()
+    return err
+
+
+@pytest.mark.parametrize("dim,P,G,T", [
+    (40, 7, 50, 33), (39, 30, 200, 64), (40, 100, 1500, 257), (39, 300, 3000, 500),
+    (40, 64, 700, 1), (40, 1, 8, 31),
+])
+def test_score_matches_oracle(amlike_device, dim, P, G, T):
+    m = synth.make_gmm(dim, P, G, seed=100 + P)
+    feats = synth.make_feats(m, T, seed=200 + T)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    assert (am.NumPdfs(), am.NumGauss(), am.Dim()) == (P, int(m["pdf_offsets"][-1]), dim)
+    got = am.LogLikelihoods(feats)
+    _check(m, feats, got)
+
+
+def test_gconsts_bit_exact_vs_oracle():
+    m = synth.make_gmm(40, 50, 600, seed=3)
+    a, _ = gmm.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    b, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    assert np.array_equal(a, b)
+
+
+def test_large_pdfs_are_split_over_waves(amlike_device):
+    """pdfs with more Gaussians than one wave holds (UBM-like) take the merge path."""
+    rng = np.random.default_rng(5)
+    sizes = np.array([700, 3, 1, 250, 97, 2, 513], dtype=np.int64)
+    m = synth.make_gmm(40, len(sizes), int(sizes.sum()), seed=9, equal_sizes=True)
+    off = np.zeros(len(sizes) + 1, dtype=np.int32)
+    np.cumsum(sizes, out=off[1:])
+    m["pdf_offsets"] = off
+    # renormalise weights per pdf
+    for j in range(len(sizes)):
+        w = rng.random(sizes[j]).astype(np.float32) + 0.05
+        m["weights"][off[j]:off[j + 1]] = w / w.sum()
+    feats = synth.make_feats(m, 150, seed=11)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    _check(m, feats, am.LogLikelihoods(feats))
+
+
+def test_strided_inputs_and_outputs(amlike_device):
+    m = synth.make_gmm(39, 40, 400, seed=21)
+    T = 77
+    base = np.zeros((T, 48), dtype=np.float32)
+    base[:, :39] = synth.make_feats(m, T, seed=22)
+    feats = base[:, :39]                      # row stride 48 floats
+    out_base = np.full((T, 64), np.nan, dtype=np.float32)
+    out = out_base[:, :40]
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    am.LogLikelihoods(feats, out=out)
+    _check(m, np.ascontiguousarray(feats), np.ascontiguousarray(out))
+    assert np.isnan(out_base[:, 40:]).all()   # padding columns untouched
+
+
+def test_device_pointer_path_unaligned_stride(amlike_device):
+    import torch
+    m = synth.make_gmm(39, 25, 260, seed=31)
+    T = 130
+    feats = synth.make_feats(m, T, seed=32)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    d_feats = torch.from_numpy(feats).cuda()          # ld = 39: not 16-byte aligned rows
+    d_out = torch.empty((T, 25), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    am.LogLikelihoodsDevice(d_feats.data_ptr(), T, 39, 39, d_out.data_ptr(), 25)
+    am.Poll()
+    _check(m, feats, d_out.cpu().numpy())
+
+
+def test_dim_mismatch_and_nonfinite_errors(amlike_device):
+    m = synth.make_gmm(40, 10, 100, seed=41)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    with pytest.raises(_lib.AmlikeError) as e:
+        am.LogLikelihoods(np.zeros((5, 39), dtype=np.float32))
+    assert e.value.code == _lib.EDIM and "Dim mismatch" in str(e.value)
+    feats = synth.make_feats(m, 40, seed=42)
+    feats[7, 3] = np.inf
+    with pytest.raises(_lib.AmlikeError) as e:
+        am.LogLikelihoods(feats)
+    assert e.value.code == _lib.ENONFINITE and "Invalid answer" in str(e.value)
+    feats[7, 3] = np.nan
+    with pytest.raises(_lib.AmlikeError) as e:
+        am.LogLikelihoods(feats)
+    assert e.value.code == _lib.ENONFINITE
+
+
+def test_zero_weight_gaussians_give_minus_inf_gconst(amlike_device):
+    """A zero weight makes gconst -inf (counted, not fatal: gmm/diag-gmm.cc:141-146);
+    the pdf's likelihood then ignores that Gaussian."""
+    m = synth.make_gmm(40, 6, 60, seed=51)
+    m["weights"][3] = 0.0
+    gc, bad = gmm.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    assert bad == 1 and np.isneginf(gc[3])
+    feats = synth.make_feats(m, 64, seed=52)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    _check(m, feats, am.LogLikelihoods(feats))
+
+
+def test_component_loglikes_match_oracle(amlike_device):
+    """DiagGmm::LogLikelihoods(Matrix): per-Gaussian scores of one pdf / of all."""
+    m = synth.make_gmm(40, 12, 300, seed=61)
+    feats = synth.make_feats(m, 90, seed=62)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    off = m["pdf_offsets"]
+    got = am.ComponentLogLikelihoods(feats, 4, 5)
+    want = oracle.diag_gmm_loglikes_mat(am.gconsts[off[4]:off[5]], m["means_invvars"][off[4]:off[5]],
+                                        m["inv_vars"][off[4]:off[5]], feats)
+    assert np.abs(got - want).max() < 1e-3
+    got = am.ComponentLogLikelihoods(feats)
+    want = oracle.diag_gmm_loglikes_mat(am.gconsts, m["means_invvars"], m["inv_vars"], feats)
+    assert np.abs(got - want).max() < 1e-3
+
+
+def test_rm_tri1_shape_full_parity(amlike_device):
+    """The rm tri1 configuration (D=39, 1500 pdfs, 9000 Gaussians) on 2000 frames."""
+    D, P, G = synth.GMM_CONFIGS["rm_tri1"]
+    m = synth.make_gmm(D, P, G, seed=777)
+    feats = synth.make_feats(m, 2000, seed=778)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    _check(m, feats, am.LogLikelihoods(feats))
