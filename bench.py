@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: acoustic frames/sec of the GMM scoring path (and, as a
+second figure on the same line, of the nnet2 p-norm forward) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch: the rank's shard of synthetic
+utterances (lengths ~U[200,1500], concatenated frame-wise, resident in HBM)
+scored against the swbd-tri4-shaped GMM (D=40, 8600 pdfs, 200000 Gaussians),
+dense [T x 8600] log-likelihoods left in HBM.  Utterances are sharded over
+ranks (one process per GPU, the reference's JOB=1:$nj practice); there is no
+data-path collective.  After the timed region the ranks all-reduce (RCCL)
+{sum of best-pdf log-likelihood, frames}, the analogue of the summary the
+reference binaries log.
+
+The line also carries
+  roofline      dominant kernel's algorithmic FLOP / its mean duration measured
+                with HIP events on the launch stream, against the fp32 MFMA peak;
+  cpu_baseline  the real reference library (oracle/_ref, kind "reference") or the
+                C restatement (kind "port") timed on a bounded sample, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from kaldi_amd import _lib, gmm, synth
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def shard_utterances(lengths, world):
+    """Longest-processing-time-first assignment of utterances to ranks."""
+    order = np.argsort(-lengths, kind="stable")
+    load = np.zeros(world, dtype=np.int64)
+    owner = np.empty(len(lengths), dtype=np.int64)
+    for i in order:
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += lengths[i]
+    return owner
+
+
+def cpu_baseline_gmm(model, gconsts, dim, seconds_target=15.0):
+    """Times the reference CPU path on a bounded sample of the same workload."""
+    import oracle
+    from oracle import kaldi_io as kio
+    est_fps = 86.0 * 200000.0 / float(model["pdf_offsets"][-1])  # 1-thread reference on C3: 86 frames/s
+    n = int(max(32, min(4000, seconds_target * est_fps)))
+    feats = synth.make_feats(model, n, seed=778)
+    if oracle.have_ref():
+        off = model["pdf_offsets"]
+        pdfs = [dict(weights=model["weights"][off[j]:off[j + 1]],
+                     means_invvars=model["means_invvars"][off[j]:off[j + 1]],
+                     inv_vars=model["inv_vars"][off[j]:off[j + 1]]) for j in range(len(off) - 1)]
+        with tempfile.TemporaryDirectory() as d:
+            with kio.open_out(os.path.join(d, "am.mdl"), True) as f:
+                kio.write_am_diag_gmm(f, True, dim, pdfs, with_gconsts=False)
+            kio.write_ark(os.path.join(d, "feats.ark"), [("sample", feats)])
+            out = oracle.ref_driver("gmm-likes", os.path.join(d, "am.mdl"),
+                                    "ark:" + os.path.join(d, "feats.ark"),
+                                    "ark:" + os.path.join(d, "out.ark"))
+        secs = float(out.split()[1])
+        kind = "reference"
+    else:
+        t0 = time.time()
+        oracle.gmm_compute_likes(gconsts, model["means_invvars"], model["inv_vars"],
+                                 model["pdf_offsets"], feats)
+        secs = time.time() - t0
+        kind = "port"
+    return {"value": n / secs, "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": "%d frames of the same synthetic workload, gmm-compute-likes loop, 1 thread, %.1f s" % (n, secs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="swbd_tri4", choices=sorted(synth.GMM_CONFIGS))
+    ap.add_argument("--utts-per-gpu", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nnet", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    _lib.check(_lib.lib().amlike_init(dev.index))
+
+    D, P, G = synth.GMM_CONFIGS[args.config]
+    model = synth.make_gmm(D, P, G, seed=777)
+    G = int(model["pdf_offsets"][-1])
+    am = gmm.AmDiagGmm(model["weights"], model["means_invvars"], model["inv_vars"],
+                       model["pdf_offsets"])
+
+    # Weak scaling: utts-per-gpu utterances per rank, sharded by utterance.
+    lengths = synth.utterance_lengths(args.utts_per_gpu * world, 200, 1500, seed=779)
+    owner = shard_utterances(lengths, world)
+    mine = np.nonzero(owner == rank)[0]
+    T = int(lengths[mine].sum())
+    ldp = (D + 3) // 4 * 4
+    feats = np.zeros((T, ldp), np.float32)
+    feats[:, :D] = synth.make_feats(model, T, seed=1000 + rank)
+    d_feats = torch.from_numpy(feats).to(dev)
+    d_out = torch.empty((T, P), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        am.LogLikelihoodsDevice(d_feats.data_ptr(), T, ldp, D, d_out.data_ptr(), P, stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    am.Poll(stream)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    am.Poll(stream)  # raises if any log-likelihood was NaN/Inf
+
+    # Summary statistics, all-reduced like the reference binaries' totals.
+    stats = torch.stack([d_out.max(dim=1).values.double().sum(),
+                         torch.tensor(float(T), dtype=torch.float64, device=dev),
+                         torch.tensor(elapsed, dtype=torch.float64, device=dev)])
+    if dist is not None:
+        tmax = stats[2:3].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats[:2], op=dist.ReduceOp.SUM)
+        elapsed = float(tmax.item())
+    tot_like, tot_frames = float(stats[0].item()), float(stats[1].item())
+
+    # Dominant kernel, timed live with HIP events on the launch stream.
+    ms = am.TimeScoreDevice(d_feats.data_ptr(), T, ldp, D, d_out.data_ptr(), P, 10, stream)
+    flop_per_frame = 2.0 * (2 * D + 1) * G
+    achieved = flop_per_frame * T / (ms * 1e-3) / 1e12
+
+    if rank == 0:
+        value = tot_frames * args.steps / elapsed
+        line = {
+            "metric": "acoustic frames/sec", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "%s GMM gmm-compute-likes: D=%d, %d pdfs, %d Gaussians; %d utterances/GPU "
+                            "(%d frames on rank 0) per step, dense [T x P] log-likelihoods kept in HBM"
+                            % (args.config, D, P, G, args.utts_per_gpu, T),
+                "parallelism": "utterance-sharded x%d, no data-path collective" % world,
+                "kernel": am.kernel_info(),
+                "avg_best_pdf_loglike_per_frame": tot_like / tot_frames,
+            },
+            "roofline": {
+                "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "kernel_ms": ms, "flop_per_frame": flop_per_frame,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_gmm(model, am.gconsts, D)
+        else:
+            line["cpu_baseline"] = None
+        if not args.no_nnet:
+            try:
+                from kaldi_amd import nnet_bench
+                line["config"]["nnet2_pnorm"] = nnet_bench.run(dev, stream, world)
+            except ImportError:
+                pass
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

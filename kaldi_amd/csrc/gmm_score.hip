@@ -385,8 +385,8 @@ struct Variant {
 // Register-stationary instantiations.  NT*D model registers per lane:
 // W=4 (one wave per SIMD, 512 registers) or W=8 (two waves per SIMD, 256 registers).
 static const Variant kVariants[] = {
-    AMLIKE_VARIANT(40, 6, 4), AMLIKE_VARIANT(39, 6, 4),
     AMLIKE_VARIANT(40, 3, 8), AMLIKE_VARIANT(39, 3, 8),
+    AMLIKE_VARIANT(40, 6, 4), AMLIKE_VARIANT(39, 6, 4),
 };
 
 struct Piece {

@@ -1,0 +1,36 @@
+"""Ad-hoc timing of the GMM scoring kernel variants on one GPU (tuning aid)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from kaldi_amd import _lib, gmm, synth
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "swbd_tri4"
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+variants = sys.argv[3].split(",") if len(sys.argv) > 3 else ["6x4", "3x8"]
+D, P, G = synth.GMM_CONFIGS[cfg]
+t0 = time.time()
+m = synth.make_gmm(D, P, G, seed=777)
+feats = synth.make_feats(m, T, seed=778)
+print("model+feats built in %.1fs  G=%d sizes: max %d" % (time.time() - t0, m["pdf_offsets"][-1],
+      np.diff(m["pdf_offsets"]).max()), flush=True)
+_lib.check(_lib.lib().amlike_init(0))
+ldp = (D + 3) // 4 * 4
+fpad = np.zeros((T, ldp), np.float32)
+fpad[:, :D] = feats
+d_feats = torch.from_numpy(fpad).cuda()
+d_out = torch.empty((T, P), dtype=torch.float32, device="cuda")
+flop = 2.0 * (2 * D + 1) * G * T
+for v in variants:
+    os.environ["AMLIKE_GMM_VARIANT"] = v
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    for it in range(2):
+        ms = am.TimeScoreDevice(d_feats.data_ptr(), T, ldp, D, d_out.data_ptr(), P, 5)
+    am.Poll()
+    print("%s  %s\n   %.3f ms/launch  %.3f Mframes/s  %.1f TFLOP/s (%.1f%% of 157.3)" % (
+        v, am.kernel_info(), ms, T / ms / 1e3, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100), flush=True)
+    am.close()
