@@ -35,7 +35,11 @@ import torch
 
 from kaldi_amd import _lib, gmm, synth
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
+# The shipped kernel forms every fp32-grade product from 6 bf16 partial products
+# (bf16x3 split of both operands), so the matrix pipe bounds it at peak / 6.
+BF16X3_PRODUCTS = 6
 
 
 def shard_utterances(lengths, world):
@@ -159,6 +163,12 @@ def main():
     ms = am.TimeScoreDevice(d_feats.data_ptr(), T, ldp, D, d_out.data_ptr(), P, 10, stream)
     flop_per_frame = 2.0 * (2 * D + 1) * G
     achieved = flop_per_frame * T / (ms * 1e-3) / 1e12
+    if "bf16x3" in am.kernel_info():
+        peak = BF16_MFMA_PEAK_TFLOPS / BF16X3_PRODUCTS
+        peak_basis = "bf16 MFMA dense peak 2500 TFLOP/s / 6 bf16 partial products per fp32-grade product"
+    else:
+        peak = FP32_MFMA_PEAK_TFLOPS
+        peak_basis = "fp32 MFMA dense peak"
 
     if rank == 0:
         value = tot_frames * args.steps / elapsed
@@ -176,9 +186,11 @@ def main():
                 "avg_best_pdf_loglike_per_frame": tot_like / tot_frames,
             },
             "roofline": {
-                "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "bound": "mfma", "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                 "kernel_ms": ms, "flop_per_frame": flop_per_frame,
+                "peak_basis": peak_basis,
+                "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

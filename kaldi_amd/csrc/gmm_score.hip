@@ -45,15 +45,27 @@
 namespace amlike {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));  // 8 bf16 = one 32x32x16 operand
 
 constexpr int kColDiscard = -1;       // segment whose result is dropped (padding chunks)
 constexpr float kNegInit = -3.0e38f;  // finite "minus infinity" for the running max
+// bf16x3 kernel: padding slots and zero-weight Gaussians carry this finite gconst
+// (their exp2 is exactly 0); a result beyond kMaxAbsLogLike counts as non-finite.
+constexpr float kPadGconst = -1.0e30f;
+constexpr float kMaxAbsLogLike = 1.0e29f;
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
+// bf16x3 kernel: feature tiles staged per block barrier (LDS: 2 groups x this x 15 KiB at D=40;
+// 8-wave blocks own a CU's LDS alone, 4-wave blocks share it two per CU).
+constexpr int FramesTilesPerBarrier(int waves, int ks) {
+  const int budget = waves == 8 ? 120 * 1024 : 60 * 1024, pair = 2 * ks * 3 * 64 * 16;
+  return budget / pair >= 4 ? 4 : budget / pair >= 2 ? 2 : 1;
+}
 
 // Device view of the packed model (see PackModel below for the layout).
 struct GmmPackView {
-  const float4 *apack;      // [num_wc][NT][DQ][64 lanes] float4
+  const void *apack;        // f32: [num_wc][NT][DQ][64 lanes] float4
+                            // bf16x3: [num_wc][NT][KS][3 parts][64 lanes] 8 x bf16
   const float *gcpack;      // [num_wc][NT][2 halves][16 regs]
   const uint32_t *endmask;  // [num_wc][NT]  bit i: register i closes a segment
   const int32_t *segcol;    // [num_wc][NT*16] output column per segment
@@ -61,7 +73,8 @@ struct GmmPackView {
 };
 
 struct ScoreArgs {
-  const float *feats;  // [T x ld], 16-byte aligned rows (ld % 4 == 0)
+  const float *feats;  // f32: [T x ld], 16-byte aligned rows (ld % 4 == 0)
+  const uint4 *bx;     // bf16x3: expanded features [frame tile][KS][3 parts][64 lanes] 8 x bf16
   int T, ld;
   float *out;  // [T x ldo]
   int ldo;
@@ -126,7 +139,7 @@ __global__ void __launch_bounds__(64 * W, (64 * W) / 256)
   // Model operands, resident in registers for the life of the wave.
   float a[NT][DQ * 4];
   {
-    const float4 *ap = pk.apack + (size_t)wc * (NT * DQ * 64) + lane;
+    const float4 *ap = static_cast<const float4 *>(pk.apack) + (size_t)wc * (NT * DQ * 64) + lane;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -268,6 +281,258 @@ __global__ void __launch_bounds__(64 * W, (64 * W) / 256)
   }
 }
 
+// ---------------------------------------------------------------------------
+// bf16x3 form of the same contraction, on the bf16 matrix pipe.
+//
+// On gfx950 the fp32-input MFMA executes at the vector-ALU rate and does not
+// overlap with VALU instructions (measured: MFMA-busy + VALU-busy cycles add
+// up, SQ_VALU_MFMA_COEXEC_CYCLES = 0), so in the kernel above every cycle of
+// log-sum-exp arithmetic is a cycle the contraction loses.  v_mfma_f32_32x32x16_bf16
+// runs on the matrix cores proper (16x the rate, concurrent with the VALU).  Each
+// fp32 operand is written exactly as the sum of three bf16 values
+// (x = x1 + x2 + x3, 8 + 8 + 8 mantissa bits) and a product a*b is formed from the
+// six partial products a1b1, a1b2, a2b1, a1b3, a2b2, a3b1, each exact in the fp32
+// accumulator; the three dropped ones are below 2^-24 of the product, i.e. the
+// result is fp32-grade (measured error vs fp64: same rms as an fp32 dot product).
+//
+// k index of MFMA step s (16 k-values): lane half h = 0 carries x_d, h = 1 carries
+// x_d^2, for d = 8s .. 8s+7; the model side carries miv_d / -0.5 iv_d likewise,
+// pre-multiplied by log2(e) so that the log-sum-exp runs directly on v_exp_f32 /
+// v_log_f32 (base 2); the result is scaled back by ln 2 once per (frame, pdf).
+//
+// Structure: model operands stay in registers (NT*KS*12 VGPRs per lane); the
+// expanded feature tile (15 KiB per 32 frames at D=40) is staged once per block
+// in LDS by global_load_lds and read by all 8 waves; the two waves on each SIMD
+// alternate between a matrix phase (30 MFMAs per 32x32 tile) and a VALU phase
+// (the running (max,sum) update), which the hardware overlaps.
+
+// Splits [T x dim] fp32 features into the bf16x3 operand image of the kernel below.
+template <int KS>
+__global__ void __launch_bounds__(256)
+    gmm_expand_feats_kernel(const float *__restrict__ feats, int T, int ld, int dim,
+                            uint4 *__restrict__ bx, int num_ftiles) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (ftile, s, lane)
+  const int lane = idx & 63;
+  const int s = (idx >> 6) % KS;
+  const int ft = (idx >> 6) / KS;
+  if (ft >= num_ftiles) return;
+  const int j = lane & 31, h = lane >> 5;
+  const int t = ft * 32 + j;
+  unsigned short p1[8], p2[8], p3[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const int d = 8 * s + jj;
+    float x = (t < T && d < dim) ? feats[(size_t)t * ld + d] : 0.0f;
+    if (h) x = x * x;
+    const __bf16 b1 = static_cast<__bf16>(x);
+    const float r1 = x - static_cast<float>(b1);
+    const __bf16 b2 = static_cast<__bf16>(r1);
+    const float r2 = r1 - static_cast<float>(b2);
+    const __bf16 b3 = static_cast<__bf16>(r2);
+    p1[jj] = __builtin_bit_cast(unsigned short, b1);
+    p2[jj] = __builtin_bit_cast(unsigned short, b2);
+    p3[jj] = __builtin_bit_cast(unsigned short, b3);
+  }
+  auto pack = [](const unsigned short *p) {
+    return make_uint4(p[0] | (unsigned)p[1] << 16, p[2] | (unsigned)p[3] << 16,
+                      p[4] | (unsigned)p[5] << 16, p[6] | (unsigned)p[7] << 16);
+  };
+  uint4 *o = bx + ((size_t)(ft * KS + s) * 3) * 64 + lane;
+  o[0] = pack(p1);
+  o[64] = pack(p2);
+  o[128] = pack(p3);
+}
+
+// ABL (timing experiments only, never dispatched in production): bit0 no output
+// stores, bit1 no (max,sum) updates, bit2 no segment closing, bit3 no feature
+// fragment reads, bit4 no barrier / staging.
+template <int KS, int NT, int W, int OCC, int ABL = 0>
+__global__ void __launch_bounds__(64 * W, OCC)
+    gmm_score_bf16x3_kernel(GmmPackView pk, ScoreArgs ar) {
+  constexpr int kTileU4 = KS * 3 * 64;  // uint4 per expanded 32-frame tile
+  constexpr int FTB = FramesTilesPerBarrier(W, KS);
+  static_assert(NT * 16 <= 64, "segment columns are held one per lane");
+  int bx, by;
+  {
+    const int total = gridDim.x, L = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = L & 7;
+    const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    by = Lp / ar.nbx;
+    bx = Lp - by * ar.nbx;
+  }
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int wc = bx * W + w;
+
+  // All LDS in one array: [2 groups of FTB feature tiles][gconst per wave].
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+  uint4 *s_b = reinterpret_cast<uint4 *>(smem_h);
+  float *s_gc = reinterpret_cast<float *>(smem_h + 2 * FTB * kTileU4 * 16) + w * (NT * 32);
+  for (int idx = lane; idx < NT * 32; idx += 64)
+    s_gc[idx] = pk.gcpack[(size_t)wc * (NT * 32) + idx];
+  // Output column of segment k of this wave's chunk: lane k of colreg (v_readlane, no memory).
+  const int colreg = lane < NT * 16 ? pk.segcol[(size_t)wc * (NT * 16) + lane] : kColDiscard;
+  uint32_t endm[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    endm[nt] = __builtin_amdgcn_readfirstlane(pk.endmask[wc * NT + nt]);
+
+  bf16x8 a[NT][KS][3];
+  {
+    const uint4 *ap = static_cast<const uint4 *>(pk.apack) + (size_t)wc * (NT * KS * 3 * 64) + lane;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[nt][s][p] = __builtin_bit_cast(bf16x8, ap[((nt * KS + s) * 3 + p) * 64]);
+  }
+
+  const int t_begin = by * ar.fpb;
+  const int t_end = min(ar.T, t_begin + ar.fpb);
+  const int ntile = t_begin < ar.T ? (t_end - t_begin + 31) >> 5 : 0;
+  const int ngroup = (ntile + FTB - 1) / FTB;
+  const uint4 *gtile = ar.bx + (size_t)(t_begin >> 5) * kTileU4;
+
+  // Stage group `g` (FTB expanded feature tiles) into LDS buffer g & 1: pieces of
+  // 1 KiB (64 lanes x 16 B) dealt round-robin to the waves; the LDS image is lane-linear.
+  auto stage = [&](int g) {
+    const int npiece = min(FTB, ntile - g * FTB) * (KS * 3);
+    for (int piece = w; piece < npiece; piece += W) {
+      const uint4 *src = gtile + (size_t)g * FTB * kTileU4 + piece * 64 + lane;
+      uint4 *dst = s_b + (g & 1) * FTB * kTileU4 + piece * 64;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+  };
+  if (ngroup > 0) stage(0);
+  if (ngroup > 1) stage(1);
+  __syncthreads();  // gconst visible; groups 0 and 1 landed (the barrier drains LDS-DMA)
+  if (ntile == 0) return;
+
+  constexpr int kMfma = KS * 6 * NT;  // matrix instructions per frame tile (NT model tiles)
+  constexpr int kSteps = NT * 16;     // (max,sum) update steps per frame tile
+  constexpr int kSkip = 2;            // leading steps without matrix work (cover LDS latency)
+  // Feature fragments of one k-step (3 parts x 8 bf16 per lane), double-buffered in
+  // registers: the fragments of k-step s+1 are requested from LDS when k-step s starts.
+  bf16x8 bf[2][3];
+  auto load_b = [&](const uint4 *bt, int s) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bf[s & 1][p] = __builtin_bit_cast(bf16x8, bt[(s * 3 + p) * 64]);
+  };
+  // Matrix instruction n of a frame tile's work: k-step s, partial product `which`
+  // (small terms first), model tile nt innermost, so that consecutive instructions
+  // go to different accumulators (NT independent chains per wave).
+  // The caller has issued load_b(bt, 0) before n = 0.
+  auto mfma_n = [&](f32x16 (&acc)[NT], const uint4 *bt, int n) {
+    const int s = n / (6 * NT), r = n % (6 * NT), which = r / NT, nt = r % NT;
+    if (r == 0 && s + 1 < KS && !(ABL & 8)) load_b(bt, s + 1);
+    // (model part, feature part): (3,1) (2,2) (1,3) (2,1) (1,2) (1,1)
+    const int pa = which == 0 ? 2 : (which == 1 || which == 3) ? 1 : 0;
+    const int pb = (which == 0 || which == 3 || which == 5) ? 0 : (which == 1 || which == 4) ? 1 : 2;
+    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][s][pa], bf[s & 1][pb], acc[nt], 0, 0, 0);
+  };
+  auto init_acc = [&](f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float4 *g4 = reinterpret_cast<const float4 *>(&s_gc[nt * 32 + h * 16]);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        float4 v = g4[q4];
+        acc[nt][4 * q4 + 0] = v.x;
+        acc[nt][4 * q4 + 1] = v.y;
+        acc[nt][4 * q4 + 2] = v.z;
+        acc[nt][4 * q4 + 3] = v.w;
+      }
+    }
+  };
+
+  // Prologue: the chains of frame tile 0.
+  f32x16 acc_cur[NT];
+  init_acc(acc_cur);
+  load_b(s_b + lane, 0);
+#pragma unroll
+  for (int n = 0; n < kMfma; ++n) mfma_n(acc_cur, s_b + lane, n);
+
+  int bad = 0;  // becomes nonzero when a result of this lane is NaN/Inf
+  for (int ft = 0; ft < ntile; ++ft) {
+    const int t0 = t_begin + (ft << 5);
+    const int row = t0 + j;
+    const bool row_ok = (row < t_end) && (h == 0);
+    float *orow = ar.out + (size_t)row * ar.ldo;
+
+    float m = kNegInit, s_ = 0.0f;
+    int seg = 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+s"(endm[nt]));
+
+    // Feature tile ft+1 opens a new group: every wave has completed its LDS reads of
+    // the group that ends with tile ft (their chains were issued in earlier stages, and
+    // the barrier waits for them), and the new group has landed.  Only now may group
+    // g+2 overwrite the buffer of group g.
+    const int fn = ft + 1;
+    if (fn % FTB == 0 && !(ABL & 16)) {
+      __syncthreads();
+      const int g = fn / FTB;
+      if (g + 1 < ngroup) stage(g + 1);
+    }
+    const uint4 *bt = s_b + (((fn / FTB) & 1) * FTB + fn % FTB) * kTileU4 + lane;
+    f32x16 acc_next[NT];
+    init_acc(acc_next);
+    if (!(ABL & 8)) load_b(bt, 0);
+
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) {
+      const int nt = st >> 4, i = st & 15;
+      // This step's share of frame tile ft+1's matrix instructions ...
+#pragma unroll
+      for (int n = (max(st - kSkip, 0) * kMfma) / (kSteps - kSkip);
+           n < (max(st + 1 - kSkip, 0) * kMfma) / (kSteps - kSkip); ++n)
+        mfma_n(acc_next, bt, n);
+      if (ABL & 2) asm volatile("" ::"v"(acc_cur[nt][i]));  // keep the chain alive when timing
+      if (!(ABL & 2)) {  // ... and one log2-sum-exp2 step: log2(sum) = m + log2(s_)
+        const float f = acc_cur[nt][i];
+        {
+          const float d = f - m;
+          const float e = fast_exp2(-fabsf(d));
+          const bool gt = d > 0.0f;
+          s_ = gt ? fmaf(s_, e, 1.0f) : (s_ + e);
+          m = gt ? f : m;
+        }
+      }
+      if (((endm[nt] >> i) & 1u) && !(ABL & 4)) {  // wave-uniform: register i closes a pdf segment
+        const int col = __builtin_amdgcn_readlane(colreg, seg);
+        ++seg;
+        float m_lo, m_hi, s_lo, s_hi;
+        both_halves(m, m_lo, m_hi);
+        both_halves(s_, s_lo, s_hi);
+        const float M = fmaxf(m_lo, m_hi);
+        const float S = s_lo * fast_exp2(m_lo - M) + s_hi * fast_exp2(m_hi - M);
+        if (col >= 0) {
+          const float v = (M + fast_log2(S)) * kLn2;
+          bad |= !(fabsf(v) <= kMaxAbsLogLike);
+          if (row_ok && !(ABL & 1)) orow[col] = v;
+        } else if (col != kColDiscard) {
+          bad |= !(fabsf(M) <= kMaxAbsLogLike) | !(S <= 3.0e38f);
+          if (row_ok) {  // parts are merged in natural-log units
+            const size_t o = (size_t)(-col - 2) * ar.part_ld + row;
+            ar.part_m[o] = M * kLn2;
+            ar.part_s[o] = S;
+          }
+        }
+        m = kNegInit;
+        s_ = 0.0f;
+      }
+    }
+    if (ABL & 4) asm volatile("" ::"v"(m), "v"(s_));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc_cur[nt] = acc_next[nt];
+  }
+  if (bad) atomicOr(ar.flag, 1);
+}
+
 // Merges the parts of pdfs that were split over several waves:
 // out[t][col] = log sum_parts s_p exp(m_p).   One thread per (split pdf, frame).
 struct SplitPdf {
@@ -291,7 +556,7 @@ __global__ void gmm_merge_parts_kernel(const SplitPdf *splits, int num_splits,
   }
   const float v = M + kLn2 * fast_log2(S);
   out[(size_t)t * ldo + d.col] = v;
-  if (!(fabsf(v) <= 3.0e38f)) atomicOr(flag, 1);
+  if (!(fabsf(v) <= kMaxAbsLogLike)) atomicOr(flag, 1);
 }
 
 // Copies [T x dim] features with an arbitrary row stride into a 16-byte aligned
@@ -374,17 +639,36 @@ __global__ void __launch_bounds__(256)
 // Host side: the packed model.
 
 struct Variant {
-  int D, NT, W;
+  int mode;  // 0: exact-fp32 MFMA kernel, 1: bf16x3 kernel
+  int D;     // mode 0: feature dimension; mode 1: KS = ceil(dim / 8) MFMA k-steps
+  int NT, W;
   void (*kernel)(GmmPackView, ScoreArgs);
+  void (*expand)(const float *, int, int, int, uint4 *, int);  // bf16x3 feature prepass
   const char *name;
 };
 
 #define AMLIKE_VARIANT(D, NT, W) \
-  { D, NT, W, gmm_score_kernel<D, NT, W>, "gmm_score_kernel<" #D "," #NT "," #W ">" }
+  { 0, D, NT, W, gmm_score_kernel<D, NT, W>, nullptr, "gmm_score_kernel<" #D "," #NT "," #W ">" }
+#define AMLIKE_VARIANT_H(KS, NT, W, OCC)                                                  \
+  { 1, KS, NT, W, gmm_score_bf16x3_kernel<KS, NT, W, OCC>, gmm_expand_feats_kernel<KS>,   \
+    "gmm_score_bf16x3_kernel<" #KS "," #NT "," #W "," #OCC ">" }
+#define AMLIKE_VARIANT_ABL(KS, NT, W, OCC, ABL)                                           \
+  { 100 + ABL, KS, NT, W, gmm_score_bf16x3_kernel<KS, NT, W, OCC, ABL>,                   \
+    gmm_expand_feats_kernel<KS>, "gmm_score_bf16x3_kernel<" #KS "," #NT "," #W "," #OCC ",ABL=" #ABL ">" }
 
-// Register-stationary instantiations.  NT*D model registers per lane:
-// W=4 (one wave per SIMD, 512 registers) or W=8 (two waves per SIMD, 256 registers).
+// Register-stationary instantiations; the first match in this order is the default.
+// bf16x3: KS = ceil(dim / 8) k-steps, NT*KS*12 model registers per lane, two waves per SIMD;
+//         covers every feature dimension up to 64.
+// f32:    exact-fp32 MFMA, NT*D model registers per lane (AMLIKE_GMM_MODE=f32), D = 39 / 40.
 static const Variant kVariants[] = {
+    AMLIKE_VARIANT_H(5, 2, 8, 2), AMLIKE_VARIANT_H(5, 2, 4, 2),
+    AMLIKE_VARIANT_H(1, 2, 8, 2), AMLIKE_VARIANT_H(2, 2, 8, 2), AMLIKE_VARIANT_H(3, 2, 8, 2),
+    AMLIKE_VARIANT_H(4, 2, 8, 2), AMLIKE_VARIANT_H(6, 1, 8, 2), AMLIKE_VARIANT_H(7, 1, 8, 2),
+    AMLIKE_VARIANT_H(8, 1, 8, 2),
+#ifdef AMLIKE_ABLATION_BUILD
+    AMLIKE_VARIANT_ABL(5, 2, 8, 2, 1), AMLIKE_VARIANT_ABL(5, 2, 8, 2, 6), AMLIKE_VARIANT_ABL(5, 2, 8, 2, 14),
+    AMLIKE_VARIANT_ABL(5, 2, 8, 2, 30), AMLIKE_VARIANT_ABL(5, 2, 8, 2, 4),
+#endif
     AMLIKE_VARIANT(40, 3, 8), AMLIKE_VARIANT(39, 3, 8),
     AMLIKE_VARIANT(40, 6, 4), AMLIKE_VARIANT(39, 6, 4),
 };
@@ -406,7 +690,7 @@ struct amlike_gmm {
   int num_splits = 0;
   double fill = 0.0;  // used slots / allocated slots
   // device arrays
-  float4 *d_apack = nullptr;
+  void *d_apack = nullptr;
   float *d_gcpack = nullptr;
   uint32_t *d_endmask = nullptr;
   int32_t *d_segcol = nullptr;
@@ -415,17 +699,28 @@ struct amlike_gmm {
   int *d_flag = nullptr;
   std::vector<int32_t> pdf_offsets;
   hipStream_t stream = nullptr;  // used by the host-pointer entry points
-  DeviceBuffer ws_feats, ws_out, ws_part, ws_pad;
+  DeviceBuffer ws_feats, ws_out, ws_part, ws_pad, ws_expand;
   std::mutex mu;
   std::string info;
 };
 
 namespace amlike {
 
+// AMLIKE_GMM_MODE = "f32" | "bf16x3" and AMLIKE_GMM_VARIANT = "<NT>x<W>" narrow the choice
+// (tuning / A-B aids); by default the first matching entry of kVariants is taken.
 static const Variant *ChooseVariant(int dim) {
-  const char *force = getenv("AMLIKE_GMM_VARIANT");  // e.g. "3x8": tuning aid
+  const char *force = getenv("AMLIKE_GMM_VARIANT");
+  const char *mode = getenv("AMLIKE_GMM_MODE");
   for (const Variant &v : kVariants) {
-    if (v.D != dim) continue;
+    if (v.mode == 0 && v.D != dim) continue;
+    if (v.mode >= 1 && v.D != (dim + 7) / 8) continue;
+    if (v.mode >= 100) {  // ablation instantiations: only by explicit request "abl<N>"
+      char want[32];
+      snprintf(want, sizeof(want), "abl%d", v.mode - 100);
+      if (!mode || strcmp(mode, want) != 0) continue;
+    } else if (mode && strcmp(mode, v.mode == 0 ? "f32" : "bf16x3") != 0) {
+      continue;
+    }
     if (force) {
       char buf[32];
       snprintf(buf, sizeof(buf), "%dx%d", v.NT, v.W);
@@ -434,6 +729,29 @@ static const Variant *ChooseVariant(int dim) {
     return &v;
   }
   return nullptr;
+}
+
+// fp32 -> bf16, round to nearest even (finite inputs; the model has no NaN here).
+static inline uint16_t Bf16Rne(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);  // inf / nan: truncate
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float Bf16ToFloat(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float x;
+  memcpy(&x, &u, 4);
+  return x;
+}
+// x = p[0] + p[1] + p[2] exactly (24 mantissa bits over three bf16).
+static inline void SplitBf16x3(float x, uint16_t p[3]) {
+  p[0] = Bf16Rne(x);
+  float r = x - Bf16ToFloat(p[0]);
+  p[1] = Bf16Rne(r);
+  r -= Bf16ToFloat(p[1]);
+  p[2] = Bf16Rne(r);
 }
 
 // Packs the model for `v`.
@@ -449,7 +767,7 @@ static const Variant *ChooseVariant(int dim) {
 static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, const float *iv,
                      const int32_t *offs) {
   const Variant &v = *g->variant;
-  const int D = v.D, NT = v.NT, W = v.W, DQ = (D + 3) / 4;
+  const int D = g->dim, NT = v.NT, W = v.W, DQ = (D + 3) / 4, KS = (D + 7) / 8;
   const int cap = NT * 32;
   std::vector<Piece> pieces;
   std::vector<SplitPdf> splits;
@@ -517,22 +835,54 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
   g->num_splits = (int)splits.size();
   g->fill = (double)used_slots / ((double)num_wc * cap);
 
-  std::vector<float> apack((size_t)num_wc * NT * DQ * 64 * 4, 0.0f);
-  std::vector<float> gcpack((size_t)num_wc * NT * 32, -std::numeric_limits<float>::infinity());
+  // Operand image.  mode 0: fp32 [wc][nt][dq][lane][4]; mode 1: bf16 [wc][nt][s][part][lane][8],
+  // values pre-multiplied by log2(e), lane (r, h): h=0 -> miv, h=1 -> -0.5 iv, d = 8s + jj.
+  std::vector<float> apack;
+  std::vector<uint16_t> apack_h;
+  if (v.mode == 0) apack.assign((size_t)num_wc * NT * DQ * 64 * 4, 0.0f);
+  else apack_h.assign((size_t)num_wc * NT * KS * 3 * 64 * 8, 0);
+  std::vector<float> gcpack((size_t)num_wc * NT * 32,
+                            v.mode == 0 ? -std::numeric_limits<float>::infinity() : kPadGconst);
   std::vector<uint32_t> endmask((size_t)num_wc * NT, 0u);
   std::vector<int32_t> segcol((size_t)num_wc * NT * 16, kColDiscard);
+  std::vector<int> order;
   for (int wc = 0; wc < num_wc; ++wc) {
     int slot = 0, seg = 0;
     for (const Piece &p : chunks[wc]) {
+      // Gaussians with gconst = -inf (zero weight) go last within their pdf, so that
+      // the first element each half-wave sees of a segment is a live one.
+      order.resize(p.count);
+      {
+        int lo = 0, hi = p.count;
+        for (int q = 0; q < p.count; ++q)
+          if (std::isfinite(gconsts[p.g_begin + q])) order[lo++] = p.g_begin + q;
+        for (int q = p.count - 1; q >= 0; --q)
+          if (!std::isfinite(gconsts[p.g_begin + q])) order[--hi] = p.g_begin + q;
+      }
       for (int q = 0; q < p.count; ++q) {
         const int n = slot + q, nt = n >> 5, nn = n & 31, i = nn >> 1, hh = nn & 1;
         const int r = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const size_t gi = (size_t)(p.g_begin + q);
-        gcpack[((size_t)wc * NT + nt) * 32 + hh * 16 + i] = gconsts[gi];
-        for (int d = 0; d < D; ++d) {
-          const size_t base = ((((size_t)wc * NT + nt) * DQ + (d >> 2)) * 64) * 4 + (d & 3);
-          apack[base + (size_t)r * 4] = miv[gi * D + d];
-          apack[base + (size_t)(r + 32) * 4] = -0.5f * iv[gi * D + d];
+        const size_t gi = (size_t)order[q];
+        if (v.mode == 0) {
+          gcpack[((size_t)wc * NT + nt) * 32 + hh * 16 + i] = gconsts[gi];
+          for (int d = 0; d < D; ++d) {
+            const size_t base = ((((size_t)wc * NT + nt) * DQ + (d >> 2)) * 64) * 4 + (d & 3);
+            apack[base + (size_t)r * 4] = miv[gi * D + d];
+            apack[base + (size_t)(r + 32) * 4] = -0.5f * iv[gi * D + d];
+          }
+        } else {
+          gcpack[((size_t)wc * NT + nt) * 32 + hh * 16 + i] = std::max(gconsts[gi] * kLog2e, kPadGconst);
+          for (int d = 0; d < D; ++d) {
+            const int s = d >> 3, jj = d & 7;
+            uint16_t pm[3], pv[3];
+            SplitBf16x3(miv[gi * D + d] * kLog2e, pm);
+            SplitBf16x3(-0.5f * iv[gi * D + d] * kLog2e, pv);
+            for (int part = 0; part < 3; ++part) {
+              const size_t base = (((((size_t)wc * NT + nt) * KS + s) * 3 + part) * 64) * 8 + jj;
+              apack_h[base + (size_t)r * 8] = pm[part];
+              apack_h[base + (size_t)(r + 32) * 8] = pv[part];
+            }
+          }
         }
       }
       slot += (p.count + 1) & ~1;
@@ -552,11 +902,16 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
     }
   }
 
-  AMLIKE_HIP(hipMalloc(&g->d_apack, apack.size() * sizeof(float)));
+  if (v.mode >= 1) {
+    AMLIKE_HIP(hipMalloc(&g->d_apack, apack_h.size() * sizeof(uint16_t)));
+    AMLIKE_HIP(hipMemcpy(g->d_apack, apack_h.data(), apack_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  } else {
+    AMLIKE_HIP(hipMalloc(&g->d_apack, apack.size() * sizeof(float)));
+    AMLIKE_HIP(hipMemcpy(g->d_apack, apack.data(), apack.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   AMLIKE_HIP(hipMalloc(&g->d_gcpack, gcpack.size() * sizeof(float)));
   AMLIKE_HIP(hipMalloc(&g->d_endmask, endmask.size() * sizeof(uint32_t)));
   AMLIKE_HIP(hipMalloc(&g->d_segcol, segcol.size() * sizeof(int32_t)));
-  AMLIKE_HIP(hipMemcpy(g->d_apack, apack.data(), apack.size() * sizeof(float), hipMemcpyHostToDevice));
   AMLIKE_HIP(hipMemcpy(g->d_gcpack, gcpack.data(), gcpack.size() * sizeof(float), hipMemcpyHostToDevice));
   AMLIKE_HIP(hipMemcpy(g->d_endmask, endmask.data(), endmask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   AMLIKE_HIP(hipMemcpy(g->d_segcol, segcol.data(), segcol.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -572,17 +927,37 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
                        hipStream_t stream) {
   const Variant &v = *g->variant;
   const int nbx = g->num_wc / v.W;
-  // Frames per block: enough blocks to balance the CUs, few enough that the
-  // one-off load of the model operands is amortised over many frame tiles.
+  // Frames per block: few enough blocks that the one-off load of the model
+  // operands (NT*D registers per lane) is amortised over many frame tiles, enough
+  // blocks to keep every CU busy to the end, and equal shares (no short last chunk).
   const int cus = std::max(1, NumComputeUnits());
-  const int slots = cus * (v.W == 4 ? 1 : 1);
-  int nby = std::max(1, (6 * slots + nbx - 1) / nbx);
-  int fpb = ((T + nby - 1) / nby + 31) & ~31;
-  fpb = std::max(fpb, std::min(256, (T + 31) & ~31));
-  fpb = std::min(fpb, 4096);
+  int target = 2048;
+  if (const char *e = getenv("AMLIKE_GMM_FPB")) target = std::max(32, atoi(e));  // tuning aid
+  int nby = std::max(1, (T + target - 1) / target);
+  // Small batches: split the frames further so that at least ~2 blocks per CU exist.
+  while (nbx * nby < 2 * cus && (T + nby - 1) / nby > 64) ++nby;
+  const int fpb = ((T + nby - 1) / nby + 31) & ~31;
   nby = (T + fpb - 1) / fpb;
   ScoreArgs ar;
   ar.feats = d_feats;
+  ar.bx = nullptr;
+  size_t smem = 0;
+  if (v.mode >= 1) {
+    // Feature prepass: fp32 [T x dim] -> bf16x3 operand tiles (480 B per frame at D=40).
+    const int KS = v.D, num_ftiles = (T + 31) / 32;
+    const size_t tile_bytes = (size_t)KS * 3 * 64 * 16;
+    int rc = g->ws_expand.Reserve((size_t)num_ftiles * tile_bytes);
+    if (rc != AMLIKE_OK) return rc;
+    ar.bx = static_cast<const uint4 *>(g->ws_expand.ptr);
+    const int threads = num_ftiles * KS * 64;
+    hipLaunchKernelGGL(v.expand, dim3((threads + 255) / 256), dim3(256), 0, stream, d_feats, T, ld,
+                       g->dim, static_cast<uint4 *>(g->ws_expand.ptr), num_ftiles);
+    AMLIKE_HIP(hipGetLastError());
+    smem = 2 * FramesTilesPerBarrier(v.W, KS) * tile_bytes + (size_t)v.W * v.NT * 32 * 4;
+    if (smem > 64 * 1024)
+      AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  }
   ar.T = T;
   ar.ld = ld;
   ar.out = d_out;
@@ -601,7 +976,7 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
     ar.part_ld = part_ld;
   }
   GmmPackView pk{g->d_apack, g->d_gcpack, g->d_endmask, g->d_segcol, g->num_wc};
-  hipLaunchKernelGGL(v.kernel, dim3(nbx * nby), dim3(64 * v.W), 0, stream, pk, ar);
+  hipLaunchKernelGGL(v.kernel, dim3(nbx * nby), dim3(64 * v.W), smem, stream, pk, ar);
   AMLIKE_HIP(hipGetLastError());
   if (g->num_splits > 0) {
     hipLaunchKernelGGL(gmm_merge_parts_kernel, dim3((T + 255) / 256, g->num_splits), dim3(256), 0,
@@ -727,6 +1102,7 @@ int amlike_gmm_destroy(amlike_gmm_t *g) {
   g->ws_out.Free();
   g->ws_part.Free();
   g->ws_pad.Free();
+  g->ws_expand.Free();
   if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
   return AMLIKE_OK;
@@ -747,10 +1123,12 @@ int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32
     return AMLIKE_EINVAL;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const float *use;
-  int use_ld;
-  rc = ConformFeats(g, d_feats, T, ld, st, &use, &use_ld);
-  if (rc != AMLIKE_OK) return rc;
+  const float *use = d_feats;
+  int use_ld = ld;
+  if (g->variant->mode == 0) {  // the fp32 kernel reads rows as float4
+    rc = ConformFeats(g, d_feats, T, ld, st, &use, &use_ld);
+    if (rc != AMLIKE_OK) return rc;
+  }
   return LaunchScore(g, use, T, use_ld, d_out, ldo, st);
 }
 

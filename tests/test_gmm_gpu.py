@@ -33,6 +33,8 @@ def _check(m, feats, got, tol=TOL):
 @pytest.mark.parametrize("dim,P,G,T", [
     (40, 7, 50, 33), (39, 30, 200, 64), (40, 100, 1500, 257), (39, 300, 3000, 500),
     (40, 64, 700, 1), (40, 1, 8, 31),
+    (13, 20, 160, 100), (24, 33, 400, 70), (60, 50, 500, 130), (8, 5, 30, 40), (64, 9, 90, 65),
+    (33, 17, 300, 96), (52, 10, 200, 50),
 ])
 def test_score_matches_oracle(amlike_device, dim, P, G, T):
     m = synth.make_gmm(dim, P, G, seed=100 + P)
@@ -41,6 +43,34 @@ def test_score_matches_oracle(amlike_device, dim, P, G, T):
     assert (am.NumPdfs(), am.NumGauss(), am.Dim()) == (P, int(m["pdf_offsets"][-1]), dim)
     got = am.LogLikelihoods(feats)
     _check(m, feats, got)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_both_kernel_families(amlike_device, mode, monkeypatch):
+    """The exact-fp32 MFMA kernel and the bf16x3 kernel give the same answers."""
+    monkeypatch.setenv("AMLIKE_GMM_MODE", mode)
+    m = synth.make_gmm(40, 120, 2500, seed=71)
+    feats = synth.make_feats(m, 333, seed=72)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    got = am.LogLikelihoods(feats)
+    assert ("bf16x3" in am.kernel_info()) == (mode == "bf16x3")
+    _check(m, feats, got)
+
+
+def test_widely_spread_scores(amlike_device):
+    """Scores of one pdf's Gaussians hundreds of nats apart, and large |x|: the running
+    (max, sum) must neither overflow nor lose the dominant term."""
+    m = synth.make_gmm(40, 30, 600, seed=81)
+    m["inv_vars"][::7] *= 400.0            # some very narrow Gaussians
+    m["means_invvars"][::7] *= 400.0
+    feats = synth.make_feats(m, 200, seed=82) * 2.5
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    got = am.LogLikelihoods(feats)
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    want, st = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"], feats)
+    assert st == 0
+    # relative bar here: |scores| reach 1e5, where one fp32 ulp is already 8e-3
+    assert np.all(np.abs(got - want) <= 1e-3 + 2e-6 * np.abs(want))
 
 
 def test_gconsts_bit_exact_vs_oracle():

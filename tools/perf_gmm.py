@@ -11,7 +11,7 @@ from kaldi_amd import _lib, gmm, synth
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "swbd_tri4"
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
-variants = sys.argv[3].split(",") if len(sys.argv) > 3 else ["6x4", "3x8"]
+variants = sys.argv[3].split(",") if len(sys.argv) > 3 else ["bf16x3:3x8", "bf16x3:2x8", "f32:3x8"]
 D, P, G = synth.GMM_CONFIGS[cfg]
 t0 = time.time()
 m = synth.make_gmm(D, P, G, seed=777)
@@ -26,11 +26,16 @@ d_feats = torch.from_numpy(fpad).cuda()
 d_out = torch.empty((T, P), dtype=torch.float32, device="cuda")
 flop = 2.0 * (2 * D + 1) * G * T
 for v in variants:
+    if ":" in v:
+        os.environ["AMLIKE_GMM_MODE"], v = v.split(":")
     os.environ["AMLIKE_GMM_VARIANT"] = v
     am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
     for it in range(2):
         ms = am.TimeScoreDevice(d_feats.data_ptr(), T, ldp, D, d_out.data_ptr(), P, 5)
-    am.Poll()
+    try:
+        am.Poll()
+    except Exception as e:
+        print('poll:', e)
     print("%s  %s\n   %.3f ms/launch  %.3f Mframes/s  %.1f TFLOP/s (%.1f%% of 157.3)" % (
         v, am.kernel_info(), ms, T / ms / 1e3, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100), flush=True)
     am.close()
