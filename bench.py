@@ -200,7 +200,8 @@ def main():
         if not args.no_nnet:
             try:
                 from kaldi_amd import nnet_bench
-                line["config"]["nnet2_pnorm"] = nnet_bench.run(dev, stream, world)
+                line["config"]["nnet2_pnorm"] = nnet_bench.run(dev, stream, world,
+                                                               utts_per_gpu=args.utts_per_gpu)
             except ImportError:
                 pass
         print(json.dumps(line), flush=True)

@@ -179,6 +179,16 @@ int amlike_nnet_compute_dev(amlike_nnet_t *nnet, const float *d_feats, int32_t T
                             int32_t pad_input, int32_t mode, float prob_scale, float *d_out,
                             int32_t ldo, void *stream);
 
+/* The same for a batch of utterances laid out back to back in d_feats
+ * (utt_rows[u] input frames each; outputs back to back in d_out): every kernel of the
+ * pipeline runs once over all frames, while the edge padding and the frame splicing
+ * respect the utterance boundaries exactly as NnetComputer does per utterance
+ * (nnet2/nnet-compute.cc:74-86).  *total_out_rows (may be NULL) = rows written. */
+int amlike_nnet_compute_batch_dev(amlike_nnet_t *nnet, const float *d_feats, int32_t ld,
+                                  const int32_t *utt_rows, int32_t num_utts, int32_t pad_input,
+                                  int32_t mode, float prob_scale, float *d_out, int32_t ldo,
+                                  void *stream, int64_t *total_out_rows);
+
 /* Per-kernel timing of the last amlike_nnet_compute* call pattern: runs `iters`
  * forward passes and returns mean milliseconds per pass. */
 int amlike_nnet_time_compute_dev(amlike_nnet_t *nnet, const float *d_feats, int32_t T,

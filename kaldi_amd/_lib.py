@@ -58,6 +58,7 @@ def _declare(lib):
         "amlike_nnet_right_context": (c_int32, [c_void_p]),
         "amlike_nnet_compute": (ctypes.c_int, [c_void_p, fp, c_int32, c_int32, c_int32, c_int32, c_float, fp, c_int32]),
         "amlike_nnet_compute_dev": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p]),
+        "amlike_nnet_compute_batch_dev": (ctypes.c_int, [c_void_p, c_void_p, c_int32, ip, c_int32, c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p, POINTER(ctypes.c_int64)]),
         "amlike_nnet_time_compute_dev": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p, c_int32, POINTER(c_float)]),
     }
     for name, (res, args) in sigs.items():

@@ -1,13 +1,891 @@
-// placeholder, replaced by the nnet2 forward implementation
+// nnet2 forward pass on gfx950 (MI355X): the HIP matrix backend that replaces the
+// reference's src/cudamatrix for the ops nnet2's Propagate() uses, and the
+// amlike_nnet_* C ABI.
+//
+// What it replaces (paths relative to /root/reference/src):
+//   nnet2/nnet-compute.cc:62-106,158-165     NnetComputer (pad, layer loop), NnetComputation()
+//   nnet2/nnet-component.cc:2411-2471         SpliceComponent::Propagate    (CopyRows per offset)
+//   nnet2/nnet-component.cc:1123-1131,3028-   Affine / FixedAffine          (cublasSgemm + bias kernels)
+//   nnet2/nnet-component.cc:530-535,578-592   Pnorm (GroupPnorm), Normalize (AddDiagMat2, pow, MulRowsVec)
+//   nnet2/nnet-component.cc:905-918           Softmax (ApplySoftMaxPerRow + ApplyFloor)
+//   nnet2/nnet-component.cc:2352-2357         SumGroup (SumColumnRanges)
+//   nnet2bin/nnet-am-compute.cc:93-96         floor + log
+//   nnet2/decodable-am-nnet.h:59-69           floor, log, minus log prior, scale
+//
+// Kernels (each launch covers ALL frames of a batch of utterances):
+//   nnet_pad_splice_kernel   edge-frame padding + frame splicing in one gather
+//   nnet_gemm_bias_kernel    Y = X W^T + b on v_mfma_f32_32x32x2_f32 (exact fp32, the
+//                            same arithmetic class as the reference's sgemm), 128x128
+//                            block tile, LDS double buffer, one barrier per k-step
+//   nnet_pnorm_norm_kernel   p-norm over groups of consecutive columns, optionally fused
+//                            with the row normalisation that follows it (one HBM pass)
+//   nnet_softmax_kernel      row softmax with the row held in registers (one read), fused
+//                            with floor / log / minus log-prior / scale when it is last
+//   nnet_sumgroup_kernel, nnet_elementwise_kernel, nnet_normalize_kernel, nnet_post_kernel
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "amlike_common.h"
-extern "C" {
-int amlike_nnet_create(const amlike_component_t *, int32_t, const float *, int32_t, amlike_nnet_t **) { amlike::SetError("nnet: not built"); return AMLIKE_EINVAL; }
-int amlike_nnet_destroy(amlike_nnet_t *) { return AMLIKE_OK; }
-int32_t amlike_nnet_input_dim(const amlike_nnet_t *) { return 0; }
-int32_t amlike_nnet_output_dim(const amlike_nnet_t *) { return 0; }
-int32_t amlike_nnet_left_context(const amlike_nnet_t *) { return 0; }
-int32_t amlike_nnet_right_context(const amlike_nnet_t *) { return 0; }
-int amlike_nnet_compute(amlike_nnet_t *, const float *, int32_t, int32_t, int32_t, int32_t, float, float *, int32_t) { return AMLIKE_EINVAL; }
-int amlike_nnet_compute_dev(amlike_nnet_t *, const float *, int32_t, int32_t, int32_t, int32_t, float, float *, int32_t, void *) { return AMLIKE_EINVAL; }
-int amlike_nnet_time_compute_dev(amlike_nnet_t *, const float *, int32_t, int32_t, int32_t, int32_t, float, float *, int32_t, void *, int32_t, float *) { return AMLIKE_EINVAL; }
+
+namespace amlike {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int RoundUp(int x, int m) { return (x + m - 1) / m * m; }
+
+// Per-utterance bookkeeping of a batch: rows [in_off, in_off + in_rows) of the stage
+// input become rows [out_off, out_off + out_rows) of its output.
+struct UttMap {
+  int32_t in_off, in_rows, out_off, out_rows;
+};
+
+// out row r of utterance u = [x[r - left_pad + 0] | ... | x[r - left_pad + ns - 1]] over the
+// first `dim` columns (frame indices clamped to the utterance: the edge frames are
+// repeated, nnet2/nnet-compute.cc:74-86), then the const tail of frame r - left_pad.
+// With ns = 1 and const_dim = 0 this is a plain padded copy.
+__global__ void __launch_bounds__(256)
+    nnet_pad_splice_kernel(const float *__restrict__ in, int ld_in, const UttMap *__restrict__ utts,
+                           int num_utts, int left_pad, int ns, int dim, int const_dim,
+                           float *__restrict__ out, int ld_out, int out_dim) {
+  const int u = blockIdx.y;
+  const UttMap um = utts[u];
+  for (int r = blockIdx.x; r < um.out_rows; r += gridDim.x) {
+    float *o = out + (size_t)(um.out_off + r) * ld_out;
+    for (int c = threadIdx.x; c < ld_out; c += 256) {
+      float v = 0.0f;
+      if (c < ns * dim) {
+        const int k = c / dim, d = c - k * dim;
+        int src = r - left_pad + k;
+        src = min(max(src, 0), um.in_rows - 1);
+        v = in[(size_t)(um.in_off + src) * ld_in + d];
+      } else if (c < out_dim) {
+        int src = min(max(r - left_pad, 0), um.in_rows - 1);
+        v = in[(size_t)(um.in_off + src) * ld_in + dim + (c - ns * dim)];
+      }
+      o[c] = v;
+    }
+  }
 }
+
+// Y[M x N] = X[M x K] * W[N x K]^T + bias.  X rows are K-contiguous with stride ldx
+// (multiple of 4, columns K..Kp-1 hold zeros); W is stored [N][Kp], zero padded.
+// 256 threads = 4 waves in a 2 x 2 arrangement, each wave a 64 x 64 tile = 2 x 2 MFMA
+// tiles of 32 x 32; k-step 8.  Lane (i, h) reads 4 consecutive k (offset 4h) of row i
+// with one ds_read_b128; the four k-values feed four v_mfma_f32_32x32x2_f32 whose
+// k-slots are {k, k+4} -- the same (permuted) k order for both operands.
+__global__ void __launch_bounds__(256)
+    nnet_gemm_bias_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W,
+                          int Kp, const float *__restrict__ bias, float *__restrict__ Y, int ldy,
+                          int M, int N) {
+  __shared__ __attribute__((aligned(16))) float4 s_a[2][256];  // [buf][row*2 + kq]
+  __shared__ __attribute__((aligned(16))) float4 s_b[2][256];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = w >> 1, wc = w & 1, li = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int lrow = t >> 1, lkq = t & 1;
+  const float4 *xa = reinterpret_cast<const float4 *>(X + (size_t)min(m0 + lrow, M - 1) * ldx) + lkq;
+  const float4 *wb = reinterpret_cast<const float4 *>(W + (size_t)min(n0 + lrow, N - 1) * Kp) + lkq;
+  const int nk = Kp >> 3;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  float4 ra = xa[0], rb = wb[0];
+  s_a[0][t] = ra;
+  s_b[0][t] = rb;
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) {
+      ra = xa[(ks + 1) * 2];
+      rb = wb[(ks + 1) * 2];
+    }
+    float4 fa[2], fb[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) fa[mt] = s_a[cur][(wr * 64 + mt * 32 + li) * 2 + h];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) fb[nt] = s_b[cur][(wc * 64 + nt * 32 + li) * 2 + h];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].x, fb[nt].x, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].y, fb[nt].y, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].z, fb[nt].z, acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].w, fb[nt].w, acc[mt][nt], 0, 0, 0);
+      }
+    if (ks + 1 < nk) {
+      s_a[cur ^ 1][t] = ra;
+      s_b[cur ^ 1][t] = rb;
+    }
+    __syncthreads();
+  }
+  // Epilogue: bias, store.  Register r of tile (mt, nt): row (r&3) + 8 (r>>2) + 4h, column li.
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n0 + wc * 64 + nt * 32 + li;
+    if (n >= N) continue;
+    const float bv = bias[n];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < M) Y[(size_t)m * ldy + n] = acc[mt][nt][r] + bv;
+      }
+  }
+}
+
+// Zeroes columns [dim, ld) of a [rows x ld] buffer (the k-padding the GEMM reads).
+__global__ void nnet_zero_pad_kernel(float *buf, int rows, int ld, int dim) {
+  const int padw = ld - dim;
+  const size_t n = (size_t)rows * padw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / padw;
+    buf[r * ld + dim + (i - r * padw)] = 0.0f;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// One wave per row: out[j] = (sum_{k<gs} |x[j gs + k]|^p)^(1/p)  (matrix/kaldi-vector.cc:529-566),
+// then, when FUSE_NORM, out *= (max(sum_j out_j^2 / D, 2^-66))^-0.5  (nnet-component.cc:578-592);
+// the fused form keeps a lane's outputs in registers and needs out_dim <= 64 * kPnormKeep.
+constexpr int kPnormKeep = 8;
+__device__ __forceinline__ float group_pnorm(const float *g, int gs, float p) {
+  if (p == 2.0f) {
+    float s = 0.0f;
+    for (int k = 0; k < gs; ++k) s += g[k] * g[k];
+    return sqrtf(s);
+  }
+  if (p == 1.0f) {
+    float s = 0.0f;
+    for (int k = 0; k < gs; ++k) s += fabsf(g[k]);
+    return s;
+  }
+  if (p == 0.0f) {
+    float s = 0.0f;
+    for (int k = 0; k < gs; ++k) s += g[k] != 0.0f ? 1.0f : 0.0f;
+    return s;
+  }
+  // general p in the scaled form, which cannot overflow (the reference reaches the same
+  // value through its rescue branch when pow() overflows)
+  float mx = 0.0f;
+  for (int k = 0; k < gs; ++k) mx = fmaxf(mx, fabsf(g[k]));
+  if (!(mx > 0.0f)) return 0.0f;
+  float s = 0.0f;
+  for (int k = 0; k < gs; ++k) s += powf(fabsf(g[k]) / mx, p);
+  return mx * powf(s, 1.0f / p);
+}
+
+template <bool FUSE_NORM>
+__global__ void __launch_bounds__(256)
+    nnet_pnorm_norm_kernel(const float *__restrict__ in, int ld_in, int in_dim, int rows,
+                           int out_dim, float p, float *__restrict__ out, int ld_out,
+                           int zero_pad) {
+  extern __shared__ __attribute__((aligned(16))) float s_row[];  // [4 waves][in_dim]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int gs = in_dim / out_dim;
+  float *row = s_row + (size_t)w * in_dim;
+  for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+    const float *x = in + (size_t)r * ld_in;
+    for (int c = lane; c < in_dim; c += 64) row[c] = x[c];
+    __builtin_amdgcn_wave_barrier();
+    float *o = out + (size_t)r * ld_out;
+    if (FUSE_NORM) {
+      float keep[kPnormKeep];
+      float ss = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kPnormKeep; ++k) {
+        const int jg = lane + 64 * k;
+        keep[k] = jg < out_dim ? group_pnorm(row + jg * gs, gs, p) : 0.0f;
+        ss += keep[k] * keep[k];
+      }
+      ss = wave_sum(ss);
+      const float f = 1.0f / sqrtf(fmaxf(ss / out_dim, 1.3552527156068805e-20f));  // 2^-66
+#pragma unroll
+      for (int k = 0; k < kPnormKeep; ++k) {
+        const int jg = lane + 64 * k;
+        if (jg < out_dim) o[jg] = keep[k] * f;
+      }
+    } else {
+      for (int jg = lane; jg < out_dim; jg += 64) o[jg] = group_pnorm(row + jg * gs, gs, p);
+    }
+    if (zero_pad)
+      for (int c = out_dim + lane; c < ld_out; c += 64) o[c] = 0.0f;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Stand-alone NormalizeComponent: one wave per row.
+__global__ void __launch_bounds__(256)
+    nnet_normalize_kernel(const float *__restrict__ in, int ld_in, int dim, int rows,
+                          float *__restrict__ out, int ld_out, int zero_pad) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+    const float *x = in + (size_t)r * ld_in;
+    float ss = 0.0f;
+    for (int c = lane; c < dim; c += 64) ss += x[c] * x[c];
+    ss = wave_sum(ss);
+    const float f = 1.0f / sqrtf(fmaxf(ss / dim, 1.3552527156068805e-20f));
+    float *o = out + (size_t)r * ld_out;
+    for (int c = lane; c < dim; c += 64) o[c] = x[c] * f;
+    if (zero_pad)
+      for (int c = dim + lane; c < ld_out; c += 64) o[c] = 0.0f;
+  }
+}
+
+// mode bits for the fused output post-processing.
+constexpr int kPostFloorLog = 1;  // max(v, 1e-20) then log
+constexpr int kPostPrior = 2;     // minus log prior, times scale
+
+__device__ __forceinline__ float post_process(float v, int post, const float *log_priors, int c,
+                                              float scale) {
+  if (post & kPostFloorLog) v = __logf(fmaxf(v, 1.0e-20f));
+  if (post & kPostPrior) v = (v - log_priors[c]) * scale;
+  return v;
+}
+
+// Row softmax, one 256-thread block per row, the row held in registers (<= kSoftmaxRegs
+// per thread, i.e. rows up to 256 * kSoftmaxRegs wide): max, exp, sum, scale by 1/sum, floor
+// 1e-20 (nnet-component.cc:905-918), then the optional post-processing.
+constexpr int kSoftmaxRegs = 40;
+__global__ void __launch_bounds__(256)
+    nnet_softmax_kernel(const float *__restrict__ in, int ld_in, int dim, int rows, int post,
+                        const float *__restrict__ log_priors, float scale,
+                        float *__restrict__ out, int ld_out, int zero_pad) {
+  __shared__ float s_red[4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float *x = in + (size_t)r * ld_in;
+    float v[kSoftmaxRegs];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kSoftmaxRegs; ++k) {
+      const int c = t + k * 256;
+      v[k] = c < dim ? x[c] : -INFINITY;
+      mx = fmaxf(mx, v[k]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) s_red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    __syncthreads();
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kSoftmaxRegs; ++k) {
+      v[k] = __expf(v[k] - mx);  // exp(-inf) = 0 for the columns past dim
+      sum += v[k];
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) s_red[w] = sum;
+    __syncthreads();
+    sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    float *o = out + (size_t)r * ld_out;
+#pragma unroll
+    for (int k = 0; k < kSoftmaxRegs; ++k) {
+      const int c = t + k * 256;
+      if (c < dim) o[c] = post_process(fmaxf(v[k] * inv, 1.0e-20f), post, log_priors, c, scale);
+      else if (zero_pad && c < ld_out) o[c] = 0.0f;
+    }
+  }
+}
+
+// Softmax for rows wider than the register form holds: three passes over the row.
+__global__ void __launch_bounds__(256)
+    nnet_softmax_wide_kernel(const float *__restrict__ in, int ld_in, int dim, int rows, int post,
+                             const float *__restrict__ log_priors, float scale,
+                             float *__restrict__ out, int ld_out, int zero_pad) {
+  __shared__ float s_red[4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float *x = in + (size_t)r * ld_in;
+    float mx = -INFINITY;
+    for (int c = t; c < dim; c += 256) mx = fmaxf(mx, x[c]);
+    mx = wave_max(mx);
+    if (lane == 0) s_red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    __syncthreads();
+    float sum = 0.0f;
+    for (int c = t; c < dim; c += 256) sum += __expf(x[c] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) s_red[w] = sum;
+    __syncthreads();
+    sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    float *o = out + (size_t)r * ld_out;
+    for (int c = t; c < ld_out; c += 256) {
+      if (c < dim)
+        o[c] = post_process(fmaxf(__expf(x[c] - mx) * inv, 1.0e-20f), post, log_priors, c, scale);
+      else if (zero_pad) o[c] = 0.0f;
+    }
+  }
+}
+
+// SumGroupComponent: out[r][j] = sum of in[r][begin_j .. begin_{j+1}), plus post-processing.
+__global__ void __launch_bounds__(256)
+    nnet_sumgroup_kernel(const float *__restrict__ in, int ld_in, const int32_t *__restrict__ begins,
+                         int out_dim, int rows, int post, const float *__restrict__ log_priors,
+                         float scale, float *__restrict__ out, int ld_out, int zero_pad) {
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float *x = in + (size_t)r * ld_in;
+    float *o = out + (size_t)r * ld_out;
+    for (int j = threadIdx.x; j < ld_out; j += 256) {
+      if (j < out_dim) {
+        float s = 0.0f;
+        for (int c = begins[j]; c < begins[j + 1]; ++c) s += x[c];
+        o[j] = post_process(s, post, log_priors, j, scale);
+      } else if (zero_pad) {
+        o[j] = 0.0f;
+      }
+    }
+  }
+}
+
+// Sigmoid / Tanh / RectifiedLinear (matrix/kaldi-vector.cc:937-951, :899-913;
+// nnet-component.cc:782-788), or a pure post-processing pass (kind = 0).
+__global__ void __launch_bounds__(256)
+    nnet_elementwise_kernel(const float *__restrict__ in, int ld_in, int dim, int rows, int kind,
+                            int post, const float *__restrict__ log_priors, float scale,
+                            float *__restrict__ out, int ld_out, int zero_pad) {
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float *x = in + (size_t)r * ld_in;
+    float *o = out + (size_t)r * ld_out;
+    for (int c = threadIdx.x; c < ld_out; c += 256) {
+      if (c < dim) {
+        float v = x[c];
+        if (kind == AMLIKE_SIGMOID) {
+          v = v > 0.0f ? 1.0f / (1.0f + __expf(-v)) : __expf(v) / (__expf(v) + 1.0f);
+        } else if (kind == AMLIKE_TANH) {
+          const float e = __expf(-fabsf(v));
+          const float th = -1.0f + 2.0f / (1.0f + e * e);
+          v = v > 0.0f ? th : -th;
+        } else if (kind == AMLIKE_RELU) {
+          v = fmaxf(v, 0.0f);
+        }
+        o[c] = post_process(v, post, log_priors, c, scale);
+      } else if (zero_pad) {
+        o[c] = 0.0f;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct Stage {
+  int kind = 0;
+  int in_dim = 0, out_dim = 0;
+  int left = 0, right = 0, const_dim = 0;  // splice
+  float p = 2.0f;
+  int normalize_after = 0;  // pnorm fused with the Normalize that follows
+  float *d_w = nullptr;     // [out_dim][Kp]
+  float *d_bias = nullptr;
+  int Kp = 0;
+  int32_t *d_begins = nullptr;  // sumgroup prefix [out_dim + 1]
+};
+
+}  // namespace amlike
+
+using namespace amlike;
+
+struct amlike_nnet {
+  std::vector<Stage> stages;  // after fusion
+  int input_dim = 0, output_dim = 0, left = 0, right = 0;
+  int num_priors = 0;
+  float *d_log_priors = nullptr;
+  hipStream_t stream = nullptr;
+  DeviceBuffer ws_a, ws_b, ws_in, ws_out, ws_utts;
+  std::vector<UttMap> h_utts;
+  std::mutex mu;
+};
+
+namespace amlike {
+
+static void FreeNnet(amlike_nnet *n) {
+  for (Stage &s : n->stages) {
+    (void)hipFree(s.d_w);
+    (void)hipFree(s.d_bias);
+    (void)hipFree(s.d_begins);
+  }
+  (void)hipFree(n->d_log_priors);
+  n->ws_a.Free();
+  n->ws_b.Free();
+  n->ws_in.Free();
+  n->ws_out.Free();
+  n->ws_utts.Free();
+  if (n->stream) (void)hipStreamDestroy(n->stream);
+  delete n;
+}
+
+// Runs the pipeline over a batch of utterances laid out back to back in d_feats.
+// utt_rows[u] = input frames of utterance u.  Output rows are laid out back to back too
+// (out_rows[u] = rows - left - right when !pad_input).  Returns total output rows.
+static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *utt_rows,
+                   int num_utts, int pad_input, int mode, float prob_scale, float *d_out, int ldo,
+                   hipStream_t st, int64_t *total_out_rows) {
+  const int ctx_l = n->left, ctx_r = n->right;
+  // Row bookkeeping.  Stage 0 input rows are the caller's rows; the first Splice stage
+  // does the padding as part of its gather.  If the net has no Splice, nothing changes.
+  std::vector<UttMap> &um = n->h_utts;
+  um.resize(num_utts);
+  int64_t in_total = 0;
+  for (int u = 0; u < num_utts; ++u) {
+    if (utt_rows[u] <= 0 || (!pad_input && utt_rows[u] <= ctx_l + ctx_r)) {
+      SetError("amlike_nnet_compute: utterance %d with %d frames would give empty output", u,
+               utt_rows[u]);
+      return AMLIKE_EINVAL;
+    }
+    um[u].in_off = (int32_t)in_total;
+    um[u].in_rows = utt_rows[u];
+    in_total += utt_rows[u];
+  }
+  if (in_total > (int64_t)1 << 30) {
+    SetError("amlike_nnet_compute: batch too large");
+    return AMLIKE_EINVAL;
+  }
+  // Padding (when asked) is applied once, at the first Splice: that stage sees the
+  // utterance extended by the TOTAL context of the net on each side.
+  int pad_l = pad_input ? ctx_l : 0, pad_r = pad_input ? ctx_r : 0;
+  int post = 0;
+  if (mode == AMLIKE_NNET_LOG) post = kPostFloorLog;
+  if (mode == AMLIKE_NNET_LOGLIKES) post = kPostFloorLog | kPostPrior;
+  if ((post & kPostPrior) && n->num_priors != n->output_dim) {
+    SetError("Priors in neural network not set up.");
+    return AMLIKE_EDIM;
+  }
+  // Worst-case activation buffer: rows (with padding) x widest stage.
+  int64_t max_rows = in_total + (int64_t)num_utts * (pad_l + pad_r);
+  int max_ld = RoundUp(n->input_dim, 8);
+  for (const Stage &s : n->stages) max_ld = std::max(max_ld, RoundUp(s.out_dim, 8));
+  int rc = n->ws_a.Reserve((size_t)max_rows * max_ld * sizeof(float));
+  if (rc != AMLIKE_OK) return rc;
+  rc = n->ws_b.Reserve((size_t)max_rows * max_ld * sizeof(float));
+  if (rc != AMLIKE_OK) return rc;
+  rc = n->ws_utts.Reserve((size_t)num_utts * sizeof(UttMap));
+  if (rc != AMLIKE_OK) return rc;
+
+  // Per-utterance row maps of every gather stage, built up front and uploaded once.
+  // A net that does not start with a Splice gets a plain copy stage in front, so that
+  // every later stage sees an aligned, k-padded buffer.
+  const size_t ns = n->stages.size();
+  const bool copy_first = n->stages[0].kind != AMLIKE_SPLICE;
+  std::vector<UttMap> &maps = n->h_utts;
+  maps.clear();
+  std::vector<int64_t> gather_rows;  // output rows of each gather, in order
+  {
+    std::vector<int32_t> rows(utt_rows, utt_rows + num_utts);
+    bool pad_done = !(pad_l || pad_r);
+    auto add_gather = [&](int lp, int rp, int shrink) {
+      int64_t ioff = 0, ooff = 0;
+      for (int u = 0; u < num_utts; ++u) {
+        UttMap m;
+        m.in_off = (int32_t)ioff;
+        m.in_rows = rows[u];
+        m.out_off = (int32_t)ooff;
+        m.out_rows = rows[u] + lp + rp - shrink;
+        ioff += rows[u];
+        ooff += m.out_rows;
+        rows[u] = m.out_rows;
+        maps.push_back(m);
+      }
+      gather_rows.push_back(ooff);
+    };
+    if (copy_first) add_gather(0, 0, 0);
+    for (const Stage &s : n->stages)
+      if (s.kind == AMLIKE_SPLICE) {
+        add_gather(pad_done ? 0 : pad_l, pad_done ? 0 : pad_r, s.left + s.right);
+        pad_done = true;
+      }
+    if (!pad_done) {
+      SetError("amlike_nnet_compute: pad_input needs a SpliceComponent to carry the context");
+      return AMLIKE_EINVAL;
+    }
+  }
+  rc = n->ws_utts.Reserve(maps.size() * sizeof(UttMap) + 16);
+  if (rc != AMLIKE_OK) return rc;
+  if (!maps.empty())
+    AMLIKE_HIP(hipMemcpyAsync(n->ws_utts.ptr, maps.data(), maps.size() * sizeof(UttMap),
+                              hipMemcpyHostToDevice, st));
+  const UttMap *d_maps = static_cast<const UttMap *>(n->ws_utts.ptr);
+
+  const float *cur = d_feats;
+  int cur_ld = ld;
+  int64_t cur_rows = in_total;
+  bool padded = !(pad_l || pad_r);
+  float *bufs[2] = {static_cast<float *>(n->ws_a.ptr), static_cast<float *>(n->ws_b.ptr)};
+  int which = 0;
+  size_t gi = 0;  // next gather
+  auto launch_gather = [&](int lp, int nsplice, int dim, int const_dim, float *dst, int dst_ld,
+                           int out_dim) -> int {
+    int max_out = 0;
+    for (int u = 0; u < num_utts; ++u) max_out = std::max(max_out, maps[gi * num_utts + u].out_rows);
+    dim3 grid(std::min(max_out, 2048), num_utts);
+    hipLaunchKernelGGL(nnet_pad_splice_kernel, grid, dim3(256), 0, st, cur, cur_ld,
+                       d_maps + gi * num_utts, num_utts, lp, nsplice, dim, const_dim, dst, dst_ld,
+                       out_dim);
+    AMLIKE_HIP(hipGetLastError());
+    return AMLIKE_OK;
+  };
+  if (copy_first) {
+    float *dst = bufs[which];
+    const int dst_ld = RoundUp(n->input_dim, 8);
+    rc = launch_gather(0, 1, n->input_dim, 0, dst, dst_ld, n->input_dim);
+    if (rc != AMLIKE_OK) return rc;
+    cur = dst;
+    cur_ld = dst_ld;
+    cur_rows = gather_rows[gi++];
+    which ^= 1;
+  }
+  for (size_t si = 0; si < ns; ++si) {
+    const Stage &s = n->stages[si];
+    const bool last = (si + 1 == ns);
+    const int spost = last ? post : 0;
+    float *dst = last ? d_out : bufs[which];
+    const int dst_ld = last ? ldo : RoundUp(s.out_dim, 8);
+    const int zero_pad = last ? 0 : 1;
+    int64_t out_rows = cur_rows;
+    if (s.kind == AMLIKE_SPLICE) {
+      // The gather kernel writes whole rows of dst_ld floats; on the last stage it must
+      // stay inside out_dim.
+      rc = launch_gather(padded ? 0 : pad_l, s.left + s.right + 1, s.in_dim - s.const_dim,
+                         s.const_dim, dst, last ? s.out_dim : dst_ld, s.out_dim);
+      if (rc != AMLIKE_OK) return rc;
+      if (last && ldo != s.out_dim) {
+        SetError("amlike_nnet_compute: a net ending in a SpliceComponent needs ldo == output dim");
+        return AMLIKE_EINVAL;
+      }
+      out_rows = gather_rows[gi++];
+      padded = true;
+    } else if (s.kind == AMLIKE_AFFINE) {
+      if (cur_ld < s.Kp || (cur_ld & 3) || (reinterpret_cast<uintptr_t>(cur) & 15)) {
+        SetError("amlike_nnet_compute: internal layout error before an affine stage");
+        return AMLIKE_EINVAL;
+      }
+      dim3 grid((s.out_dim + 127) / 128, (unsigned)((cur_rows + 127) / 128));
+      hipLaunchKernelGGL(nnet_gemm_bias_kernel, grid, dim3(256), 0, st, cur, cur_ld, s.d_w, s.Kp,
+                         s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
+      AMLIKE_HIP(hipGetLastError());
+      if (!last && dst_ld != s.out_dim) {
+        hipLaunchKernelGGL(nnet_zero_pad_kernel, dim3(256), dim3(256), 0, st, dst, (int)cur_rows,
+                           dst_ld, s.out_dim);
+        AMLIKE_HIP(hipGetLastError());
+      }
+    } else if (s.kind == AMLIKE_PNORM) {
+      const int blocks = (int)std::min<int64_t>((cur_rows + 3) / 4, 8192);
+      const size_t smem = (size_t)4 * s.in_dim * sizeof(float);
+      if (s.normalize_after)
+        hipLaunchKernelGGL(nnet_pnorm_norm_kernel<true>, dim3(blocks), dim3(256), smem, st, cur, cur_ld,
+                           s.in_dim, (int)cur_rows, s.out_dim, s.p, dst, dst_ld, zero_pad);
+      else
+        hipLaunchKernelGGL(nnet_pnorm_norm_kernel<false>, dim3(blocks), dim3(256), smem, st, cur, cur_ld,
+                           s.in_dim, (int)cur_rows, s.out_dim, s.p, dst, dst_ld, zero_pad);
+      AMLIKE_HIP(hipGetLastError());
+    } else if (s.kind == AMLIKE_NORMALIZE) {
+      const int blocks = (int)std::min<int64_t>((cur_rows + 3) / 4, 8192);
+      hipLaunchKernelGGL(nnet_normalize_kernel, dim3(blocks), dim3(256), 0, st, cur, cur_ld,
+                         s.in_dim, (int)cur_rows, dst, dst_ld, zero_pad);
+      AMLIKE_HIP(hipGetLastError());
+    } else if (s.kind == AMLIKE_SOFTMAX) {
+      const int blocks = (int)std::min<int64_t>(cur_rows, 16384);
+      if (s.in_dim <= 256 * kSoftmaxRegs)
+        hipLaunchKernelGGL(nnet_softmax_kernel, dim3(blocks), dim3(256), 0, st, cur, cur_ld, s.in_dim,
+                           (int)cur_rows, spost, n->d_log_priors, prob_scale, dst, dst_ld, zero_pad);
+      else
+        hipLaunchKernelGGL(nnet_softmax_wide_kernel, dim3(blocks), dim3(256), 0, st, cur, cur_ld,
+                           s.in_dim, (int)cur_rows, spost, n->d_log_priors, prob_scale, dst, dst_ld,
+                           zero_pad);
+      AMLIKE_HIP(hipGetLastError());
+    } else if (s.kind == AMLIKE_SUMGROUP) {
+      const int blocks = (int)std::min<int64_t>(cur_rows, 16384);
+      hipLaunchKernelGGL(nnet_sumgroup_kernel, dim3(blocks), dim3(256), 0, st, cur, cur_ld, s.d_begins,
+                         s.out_dim, (int)cur_rows, spost, n->d_log_priors, prob_scale, dst, dst_ld,
+                         zero_pad);
+      AMLIKE_HIP(hipGetLastError());
+    } else {
+      const int blocks = (int)std::min<int64_t>(cur_rows, 16384);
+      hipLaunchKernelGGL(nnet_elementwise_kernel, dim3(blocks), dim3(256), 0, st, cur, cur_ld,
+                         s.in_dim, (int)cur_rows, s.kind, spost, n->d_log_priors, prob_scale, dst,
+                         dst_ld, zero_pad);
+      AMLIKE_HIP(hipGetLastError());
+    }
+    const bool fused_post = (s.kind == AMLIKE_SOFTMAX || s.kind == AMLIKE_SUMGROUP ||
+                             s.kind >= AMLIKE_SIGMOID);
+    if (last && post && !fused_post) {
+      // The last stage has no fused post-processing (e.g. an affine output): one more pass.
+      const int blocks = (int)std::min<int64_t>(out_rows, 16384);
+      hipLaunchKernelGGL(nnet_elementwise_kernel, dim3(blocks), dim3(256), 0, st, d_out, ldo,
+                         s.out_dim, (int)out_rows, 0, post, n->d_log_priors, prob_scale, d_out, ldo, 0);
+      AMLIKE_HIP(hipGetLastError());
+    }
+    cur = dst;
+    cur_ld = dst_ld;
+    cur_rows = out_rows;
+    which ^= 1;
+  }
+  if (total_out_rows) *total_out_rows = cur_rows;
+  return AMLIKE_OK;
+}
+
+}  // namespace amlike
+
+extern "C" {
+
+int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float *priors,
+                       int32_t num_priors, amlike_nnet_t **out) {
+  if (!comps || num <= 0 || !out) {
+    SetError("amlike_nnet_create: invalid argument");
+    return AMLIKE_EINVAL;
+  }
+  if (CurrentDevice() < 0) {
+    int rc = amlike_init(0);
+    if (rc != AMLIKE_OK) return rc;
+  }
+  amlike_nnet *n = new amlike_nnet;
+  n->input_dim = comps[0].input_dim;
+  int dim = comps[0].input_dim;
+  int rc = AMLIKE_OK;
+  for (int i = 0; i < num && rc == AMLIKE_OK; ++i) {
+    const amlike_component_t &c = comps[i];
+    if (c.input_dim != dim) {
+      SetError("amlike_nnet_create: component %d expects input dim %d, previous output is %d", i,
+               c.input_dim, dim);
+      rc = AMLIKE_EDIM;
+      break;
+    }
+    Stage s;
+    s.kind = c.kind;
+    s.in_dim = c.input_dim;
+    s.out_dim = c.output_dim;
+    switch (c.kind) {
+      case AMLIKE_SPLICE: {
+        s.left = c.left_context;
+        s.right = c.right_context;
+        s.const_dim = c.const_dim;
+        const int want = (c.input_dim - c.const_dim) * (1 + c.left_context + c.right_context) + c.const_dim;
+        if (c.left_context < 0 || c.right_context < 0 || c.const_dim < 0 ||
+            c.const_dim >= c.input_dim || c.output_dim != want) {
+          SetError("amlike_nnet_create: bad SpliceComponent %d", i);
+          rc = AMLIKE_EINVAL;
+        }
+        n->left += s.left;
+        n->right += s.right;
+        break;
+      }
+      case AMLIKE_AFFINE: {
+        if (!c.linear || !c.bias) {
+          SetError("amlike_nnet_create: affine component %d without parameters", i);
+          rc = AMLIKE_EINVAL;
+          break;
+        }
+        s.Kp = RoundUp(c.input_dim, 8);
+        std::vector<float> w((size_t)c.output_dim * s.Kp, 0.0f);
+        for (int r = 0; r < c.output_dim; ++r)
+          memcpy(&w[(size_t)r * s.Kp], c.linear + (size_t)r * c.input_dim, c.input_dim * sizeof(float));
+        hipError_t e = hipMalloc(&s.d_w, w.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(s.d_w, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(&s.d_bias, c.output_dim * sizeof(float));
+        if (e == hipSuccess)
+          e = hipMemcpy(s.d_bias, c.bias, c.output_dim * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+          SetError("amlike_nnet_create: %s", hipGetErrorString(e));
+          rc = e == hipErrorOutOfMemory ? AMLIKE_EOOM : AMLIKE_EHIP;
+        }
+        break;
+      }
+      case AMLIKE_PNORM:
+        s.p = c.p;
+        if (c.output_dim <= 0 || c.input_dim % c.output_dim != 0 || c.p < 0 ||
+            (size_t)4 * c.input_dim * sizeof(float) > 60 * 1024) {
+          SetError("amlike_nnet_create: bad PnormComponent %d", i);
+          rc = AMLIKE_EINVAL;
+        }
+        break;
+      case AMLIKE_SUMGROUP: {
+        if (!c.sizes) {
+          SetError("amlike_nnet_create: SumGroupComponent %d without sizes", i);
+          rc = AMLIKE_EINVAL;
+          break;
+        }
+        std::vector<int32_t> begins(c.output_dim + 1, 0);
+        for (int j = 0; j < c.output_dim; ++j) begins[j + 1] = begins[j] + c.sizes[j];
+        if (begins[c.output_dim] != c.input_dim) {
+          SetError("amlike_nnet_create: SumGroupComponent %d sizes do not add up", i);
+          rc = AMLIKE_EINVAL;
+          break;
+        }
+        hipError_t e = hipMalloc(&s.d_begins, begins.size() * sizeof(int32_t));
+        if (e == hipSuccess)
+          e = hipMemcpy(s.d_begins, begins.data(), begins.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+          SetError("amlike_nnet_create: %s", hipGetErrorString(e));
+          rc = AMLIKE_EHIP;
+        }
+        break;
+      }
+      case AMLIKE_NORMALIZE:
+      case AMLIKE_SOFTMAX:
+      case AMLIKE_SIGMOID:
+      case AMLIKE_TANH:
+      case AMLIKE_RELU:
+        if (c.input_dim != c.output_dim) {
+          SetError("amlike_nnet_create: component %d must keep the dimension", i);
+          rc = AMLIKE_EINVAL;
+        }
+        break;
+      default:
+        SetError("Unknown component type %d", c.kind);
+        rc = AMLIKE_EINVAL;
+    }
+    if (rc != AMLIKE_OK) {
+      (void)hipFree(s.d_w);
+      (void)hipFree(s.d_bias);
+      (void)hipFree(s.d_begins);
+      break;
+    }
+    // Fuse Normalize into the Pnorm before it.
+    if (c.kind == AMLIKE_NORMALIZE && !n->stages.empty() && n->stages.back().kind == AMLIKE_PNORM &&
+        !n->stages.back().normalize_after && c.input_dim <= 64 * kPnormKeep) {
+      n->stages.back().normalize_after = 1;
+    } else {
+      n->stages.push_back(s);
+    }
+    dim = c.output_dim;
+  }
+  n->output_dim = dim;
+  if (rc == AMLIKE_OK && priors && num_priors > 0) {
+    std::vector<float> lp(num_priors);
+    for (int i = 0; i < num_priors; ++i) lp[i] = logf(priors[i]);
+    hipError_t e = hipMalloc(&n->d_log_priors, num_priors * sizeof(float));
+    if (e == hipSuccess)
+      e = hipMemcpy(n->d_log_priors, lp.data(), num_priors * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      SetError("amlike_nnet_create: %s", hipGetErrorString(e));
+      rc = AMLIKE_EHIP;
+    }
+    n->num_priors = num_priors;
+  }
+  if (rc == AMLIKE_OK) {
+    hipError_t e = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      SetError("amlike_nnet_create: %s", hipGetErrorString(e));
+      rc = AMLIKE_EHIP;
+    }
+  }
+  if (rc != AMLIKE_OK) {
+    FreeNnet(n);
+    return rc;
+  }
+  *out = n;
+  return AMLIKE_OK;
+}
+
+int amlike_nnet_destroy(amlike_nnet_t *n) {
+  if (n) FreeNnet(n);
+  return AMLIKE_OK;
+}
+int32_t amlike_nnet_input_dim(const amlike_nnet_t *n) { return n ? n->input_dim : 0; }
+int32_t amlike_nnet_output_dim(const amlike_nnet_t *n) { return n ? n->output_dim : 0; }
+int32_t amlike_nnet_left_context(const amlike_nnet_t *n) { return n ? n->left : 0; }
+int32_t amlike_nnet_right_context(const amlike_nnet_t *n) { return n ? n->right : 0; }
+
+int amlike_nnet_compute_batch_dev(amlike_nnet_t *n, const float *d_feats, int32_t ld,
+                                  const int32_t *utt_rows, int32_t num_utts, int32_t pad_input,
+                                  int32_t mode, float prob_scale, float *d_out, int32_t ldo,
+                                  void *stream, int64_t *total_out_rows) {
+  if (!n || !d_feats || !d_out || !utt_rows || num_utts <= 0 || ld < n->input_dim ||
+      ldo < n->output_dim || mode < 0 || mode > 2) {
+    SetError("amlike_nnet_compute: invalid argument");
+    return AMLIKE_EINVAL;
+  }
+  return Forward(n, d_feats, ld, utt_rows, num_utts, pad_input, mode, prob_scale, d_out, ldo,
+                 static_cast<hipStream_t>(stream), total_out_rows);
+}
+
+int amlike_nnet_compute_dev(amlike_nnet_t *n, const float *d_feats, int32_t T, int32_t ld,
+                            int32_t pad_input, int32_t mode, float prob_scale, float *d_out,
+                            int32_t ldo, void *stream) {
+  return amlike_nnet_compute_batch_dev(n, d_feats, ld, &T, 1, pad_input, mode, prob_scale, d_out,
+                                       ldo, stream, nullptr);
+}
+
+int amlike_nnet_compute(amlike_nnet_t *n, const float *feats, int32_t T, int32_t ld,
+                        int32_t pad_input, int32_t mode, float prob_scale, float *out, int32_t ldo) {
+  if (!n || !feats || !out || T <= 0 || ld < n->input_dim || ldo < n->output_dim) {
+    SetError("amlike_nnet_compute: invalid argument");
+    return AMLIKE_EINVAL;
+  }
+  std::lock_guard<std::mutex> lock(n->mu);
+  const int t_out = pad_input ? T : T - n->left - n->right;
+  if (t_out <= 0) {
+    SetError("amlike_nnet_compute: %d frames give empty output", T);
+    return AMLIKE_EINVAL;
+  }
+  int rc = n->ws_in.Reserve((size_t)T * n->input_dim * sizeof(float));
+  if (rc != AMLIKE_OK) return rc;
+  rc = n->ws_out.Reserve((size_t)t_out * n->output_dim * sizeof(float));
+  if (rc != AMLIKE_OK) return rc;
+  float *din = static_cast<float *>(n->ws_in.ptr), *dout = static_cast<float *>(n->ws_out.ptr);
+  AMLIKE_HIP(hipMemcpy2DAsync(din, (size_t)n->input_dim * sizeof(float), feats,
+                              (size_t)ld * sizeof(float), (size_t)n->input_dim * sizeof(float), T,
+                              hipMemcpyHostToDevice, n->stream));
+  rc = amlike_nnet_compute_dev(n, din, T, n->input_dim, pad_input, mode, prob_scale, dout,
+                               n->output_dim, n->stream);
+  if (rc != AMLIKE_OK) return rc;
+  AMLIKE_HIP(hipMemcpy2DAsync(out, (size_t)ldo * sizeof(float), dout,
+                              (size_t)n->output_dim * sizeof(float),
+                              (size_t)n->output_dim * sizeof(float), t_out, hipMemcpyDeviceToHost,
+                              n->stream));
+  AMLIKE_HIP(hipStreamSynchronize(n->stream));
+  return AMLIKE_OK;
+}
+
+int amlike_nnet_time_compute_dev(amlike_nnet_t *n, const float *d_feats, int32_t T, int32_t ld,
+                                 int32_t pad_input, int32_t mode, float prob_scale, float *d_out,
+                                 int32_t ldo, void *stream, int32_t iters, float *ms_per_pass) {
+  if (!ms_per_pass || iters <= 0) return AMLIKE_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t e0, e1;
+  AMLIKE_HIP(hipEventCreate(&e0));
+  AMLIKE_HIP(hipEventCreate(&e1));
+  AMLIKE_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) {
+    int rc = amlike_nnet_compute_dev(n, d_feats, T, ld, pad_input, mode, prob_scale, d_out, ldo, stream);
+    if (rc != AMLIKE_OK) return rc;
+  }
+  AMLIKE_HIP(hipEventRecord(e1, st));
+  AMLIKE_HIP(hipEventSynchronize(e1));
+  float ms = 0.0f;
+  AMLIKE_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_pass = ms / iters;
+  return AMLIKE_OK;
+}
+
+}  // extern "C"

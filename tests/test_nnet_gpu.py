@@ -1,0 +1,95 @@
+"""GPU parity of the nnet2 forward path: libamlike (HIP, through the C ABI) against the
+CPU oracle.  Tolerance 1e-3 absolute on log-posteriors / pseudo-log-likelihoods (the
+benchmark definition's bar) and 1e-5 on posteriors; observed ~1e-6."""
+import numpy as np
+import pytest
+
+import oracle
+from kaldi_amd import _lib, nnet, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _nets():
+    rng = np.random.default_rng(5)
+
+    def aff(n_in, n_out):
+        return dict(type="AffineComponent",
+                    linear=(rng.normal(size=(n_out, n_in)) / np.sqrt(n_in)).astype(np.float32),
+                    bias=rng.normal(size=n_out).astype(np.float32))
+    small = synth.make_pnorm_nnet(input_dim=13, left=2, right=3, hidden=60, pnorm_out=12,
+                                  num_hidden=2, num_pdfs=100, seed=3)
+    mixup = synth.make_pnorm_nnet(input_dim=13, left=2, right=3, hidden=60, pnorm_out=12,
+                                  num_hidden=2, num_pdfs=100, mix_up=150, seed=4)
+    mid = synth.make_pnorm_nnet(input_dim=40, left=4, right=4, hidden=400, pnorm_out=40,
+                                num_hidden=3, num_pdfs=1000, seed=6)
+    misc = ([dict(type="SpliceComponent", input_dim=10, left=1, right=1, const_dim=3),
+             aff(24, 16), dict(type="SigmoidComponent", dim=16),
+             aff(16, 16), dict(type="TanhComponent", dim=16),
+             aff(16, 18), dict(type="RectifiedLinearComponent", dim=18),
+             dict(type="PnormComponent", input_dim=18, output_dim=6, p=3.0),
+             aff(6, 7), dict(type="SoftmaxComponent", dim=7)], np.full(7, 1 / 7, np.float32))
+    nosplice = ([aff(20, 33), dict(type="PnormComponent", input_dim=33, output_dim=11, p=1.0),
+                 dict(type="NormalizeComponent", dim=11), aff(11, 9),
+                 dict(type="SoftmaxComponent", dim=9)], np.full(9, 1 / 9, np.float32))
+    return dict(small=small, mixup=mixup, mid=mid, misc=misc, nosplice=nosplice)
+
+
+@pytest.mark.parametrize("name", ["small", "mixup", "mid", "misc", "nosplice"])
+@pytest.mark.parametrize("mode", [nnet.POSTERIORS, nnet.LOG, nnet.LOGLIKES])
+@pytest.mark.parametrize("pad", [True, False])
+def test_forward_matches_oracle(amlike_device, name, mode, pad):
+    comps, priors = _nets()[name]
+    net = nnet.AmNnet(comps, priors)
+    x = np.random.default_rng(11).normal(size=(37, net.InputDim())).astype(np.float32)
+    got = net.Compute(x, pad_input=pad, mode=mode, prob_scale=0.7)
+    want = oracle.nnet_compute(comps, priors, x, pad, mode, 0.7)
+    assert got.shape == want.shape
+    tol = 1e-5 if mode == nnet.POSTERIORS else 1e-3
+    assert np.abs(got - want).max() < tol
+    if mode == nnet.POSTERIORS:
+        assert np.allclose(got.sum(1), 1.0, atol=1e-4)
+    assert (got.argmax(1) == want.argmax(1)).all()
+
+
+def test_batch_respects_utterance_boundaries(amlike_device):
+    import torch
+    comps, priors = _nets()["mid"]
+    net = nnet.AmNnet(comps, priors)
+    rng = np.random.default_rng(21)
+    lens = [9, 130, 1, 57, 300]
+    utts = [rng.normal(size=(n, 40)).astype(np.float32) for n in lens]
+    want = np.concatenate([oracle.nnet_compute(comps, priors, u, True, 2, 1.0) for u in utts])
+    d_in = torch.from_numpy(np.concatenate(utts)).cuda()
+    d_out = torch.empty((sum(lens), net.OutputDim()), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    n = net.ComputeBatchDevice(d_in.data_ptr(), 40, lens, d_out.data_ptr(), net.OutputDim(),
+                               pad_input=True, mode=nnet.LOGLIKES)
+    torch.cuda.synchronize()
+    assert n == sum(lens)
+    assert np.abs(d_out.cpu().numpy() - want).max() < 1e-3
+
+
+def test_swbd_pnorm_shape(amlike_device):
+    """The benchmark topology (4 x 2000 -> 200 p-norm, 8600-way softmax) on 300 frames."""
+    comps, priors = synth.make_pnorm_nnet(seed=780)
+    net = nnet.AmNnet(comps, priors)
+    assert (net.InputDim(), net.OutputDim(), net.LeftContext(), net.RightContext()) == (40, 8600, 4, 4)
+    x = np.random.default_rng(31).normal(size=(300, 40)).astype(np.float32)
+    got = net.Compute(x, mode=nnet.LOGLIKES)
+    want = oracle.nnet_compute(comps, priors, x, True, 2, 1.0)
+    assert np.abs(got - want).max() < 1e-3
+    assert (got.argmax(1) == want.argmax(1)).mean() >= 0.9999
+
+
+def test_errors(amlike_device):
+    comps, priors = _nets()["small"]
+    net = nnet.AmNnet(comps, priors)
+    with pytest.raises(ValueError):
+        net.Compute(np.zeros((5, 13), np.float32), pad_input=False)   # 5 frames < context 6
+    bad = [dict(type="PnormComponent", input_dim=10, output_dim=3, p=2.0)]
+    with pytest.raises(_lib.AmlikeError):
+        nnet.AmNnet(bad, None)
+    with pytest.raises(_lib.AmlikeError) as e:
+        nnet.AmNnet(comps, priors[:50]).Compute(np.zeros((20, 13), np.float32), mode=nnet.LOGLIKES)
+    assert "Priors" in str(e.value)
