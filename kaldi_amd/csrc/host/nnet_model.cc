@@ -1,0 +1,267 @@
+// Host-side nnet2 model classes (see nnet_model.h).
+#include "nnet_model.h"
+
+namespace kaldi_amd {
+namespace nnet2 {
+
+// Reads what follows "<Type>" of a NonlinearComponent (nnet2/nnet-component.cc:365-388).
+static void ReadNonlinear(std::istream &is, bool binary, Component *c) {
+  const std::string beg = "<" + c->type + ">", end = "</" + c->type + ">";
+  ExpectOneOrTwoTokens(is, binary, beg, "<Dim>");
+  ReadBasicType(is, binary, &c->input_dim);
+  c->output_dim = c->input_dim;
+  std::string tok;
+  ReadToken(is, binary, &tok);
+  if (tok == "<ValueSum>") {
+    Vector tmp;
+    tmp.Read(is, binary);
+    ExpectToken(is, binary, "<DerivSum>");
+    tmp.Read(is, binary);
+    ExpectToken(is, binary, "<Count>");
+    double count;
+    ReadBasicType(is, binary, &count);
+    ExpectToken(is, binary, end.c_str());
+  } else if (tok == "<Counts>") {
+    Vector tmp;
+    tmp.Read(is, binary);
+    ExpectToken(is, binary, end.c_str());
+  } else if (tok != end) {
+    KALDI_AMD_ERR("Expected " << end << ", got " << tok);
+  }
+}
+
+static void ReadAffineHead(std::istream &is, bool binary, Component *c) {
+  const std::string beg = "<" + c->type + ">";
+  ExpectOneOrTwoTokens(is, binary, beg, "<LearningRate>");
+  float lr;
+  ReadBasicType(is, binary, &lr);
+  ExpectToken(is, binary, "<LinearParams>");
+  c->linear.Read(is, binary);
+  ExpectToken(is, binary, "<BiasParams>");
+  c->bias.Read(is, binary);
+  c->output_dim = c->linear.NumRows();
+  c->input_dim = c->linear.NumCols();
+  if (c->bias.Dim() != c->output_dim) KaldiErr("Affine component: bias / linear parameter mismatch");
+}
+
+// nnet2/nnet-component.cc:33-43 ReadNew + the Read() of each supported type.
+static Component ReadComponent(std::istream &is, bool binary) {
+  std::string token;
+  ReadToken(is, binary, &token);
+  if (token.size() < 3 || token.front() != '<' || token.back() != '>')
+    KALDI_AMD_ERR("Unknown component type " << token);
+  Component c;
+  c.type = token.substr(1, token.size() - 2);
+  const std::string end = "</" + c.type + ">";
+  std::string tok;
+  if (c.type == "SpliceComponent") {  // :2567-2577
+    c.kind = AMLIKE_SPLICE;
+    ExpectOneOrTwoTokens(is, binary, token, "<InputDim>");
+    ReadBasicType(is, binary, &c.input_dim);
+    ExpectToken(is, binary, "<LeftContext>");
+    ReadBasicType(is, binary, &c.left_context);
+    ExpectToken(is, binary, "<RightContext>");
+    ReadBasicType(is, binary, &c.right_context);
+    ExpectToken(is, binary, "<ConstComponentDim>");
+    ReadBasicType(is, binary, &c.const_dim);
+    ExpectToken(is, binary, end.c_str());
+    c.output_dim = (c.input_dim - c.const_dim) * (1 + c.left_context + c.right_context) + c.const_dim;
+  } else if (c.type == "FixedAffineComponent") {  // :3063-3069
+    c.kind = AMLIKE_AFFINE;
+    ExpectOneOrTwoTokens(is, binary, token, "<LinearParams>");
+    c.linear.Read(is, binary);
+    ExpectToken(is, binary, "<BiasParams>");
+    c.bias.Read(is, binary);
+    ExpectToken(is, binary, end.c_str());
+    c.output_dim = c.linear.NumRows();
+    c.input_dim = c.linear.NumCols();
+  } else if (c.type == "AffineComponent") {  // :1162-1192
+    c.kind = AMLIKE_AFFINE;
+    ReadAffineHead(is, binary, &c);
+    ReadToken(is, binary, &tok);
+    if (tok == "<AvgInput>") {
+      Vector avg;
+      avg.Read(is, binary);
+      ExpectToken(is, binary, "<AvgInputCount>");
+      float cnt;
+      ReadBasicType(is, binary, &cnt);
+      ReadToken(is, binary, &tok);
+    }
+    if (tok == "<IsGradient>") {
+      bool g;
+      ReadBasicType(is, binary, &g);
+      ExpectToken(is, binary, end.c_str());
+    } else if (tok != end) {
+      KALDI_AMD_ERR("Expected " << end << ", got " << tok);
+    }
+  } else if (c.type == "AffineComponentPreconditioned") {  // :1309-1337
+    c.kind = AMLIKE_AFFINE;
+    ReadAffineHead(is, binary, &c);
+    float f;
+    ExpectToken(is, binary, "<Alpha>");
+    ReadBasicType(is, binary, &f);
+    ReadToken(is, binary, &tok);
+    if (tok == "<MaxChange>") {
+      ReadBasicType(is, binary, &f);
+      ExpectToken(is, binary, end.c_str());
+    } else if (tok != end) {
+      KALDI_AMD_ERR("Expected " << end << ", got " << tok);
+    }
+  } else if (c.type == "AffineComponentPreconditionedOnline") {  // :1541-1579
+    c.kind = AMLIKE_AFFINE;
+    ReadAffineHead(is, binary, &c);
+    int32 i;
+    float f;
+    ReadToken(is, binary, &tok);
+    if (tok == "<Rank>") {
+      ReadBasicType(is, binary, &i);
+    } else if (tok == "<RankIn>") {
+      ReadBasicType(is, binary, &i);
+      ExpectToken(is, binary, "<RankOut>");
+      ReadBasicType(is, binary, &i);
+    } else {
+      KALDI_AMD_ERR("Expected <Rank> or <RankIn>, got " << tok);
+    }
+    ReadToken(is, binary, &tok);
+    if (tok == "<UpdatePeriod>") {
+      ReadBasicType(is, binary, &i);
+      ExpectToken(is, binary, "<NumSamplesHistory>");
+    } else if (tok != "<NumSamplesHistory>") {
+      KALDI_AMD_ERR("Expected <NumSamplesHistory>, got " << tok);
+    }
+    ReadBasicType(is, binary, &f);
+    ExpectToken(is, binary, "<Alpha>");
+    ReadBasicType(is, binary, &f);
+    ExpectToken(is, binary, "<MaxChangePerSample>");
+    ReadBasicType(is, binary, &f);
+    ExpectToken(is, binary, end.c_str());
+  } else if (c.type == "PnormComponent") {  // :548-556
+    c.kind = AMLIKE_PNORM;
+    ExpectOneOrTwoTokens(is, binary, token, "<InputDim>");
+    ReadBasicType(is, binary, &c.input_dim);
+    ExpectToken(is, binary, "<OutputDim>");
+    ReadBasicType(is, binary, &c.output_dim);
+    ExpectToken(is, binary, "<P>");
+    ReadBasicType(is, binary, &c.p);
+    ExpectToken(is, binary, end.c_str());
+  } else if (c.type == "SumGroupComponent") {  // :2322-2328 (closing token without the slash)
+    c.kind = AMLIKE_SUMGROUP;
+    ExpectOneOrTwoTokens(is, binary, token, "<Sizes>");
+    ReadIntegerVector(is, binary, &c.sizes);
+    ExpectToken(is, binary, "<SumGroupComponent>");
+    c.output_dim = static_cast<int32>(c.sizes.size());
+    c.input_dim = 0;
+    for (int32 s : c.sizes) {
+      if (s <= 0) KaldiErr("SumGroupComponent: sizes must be positive");
+      c.input_dim += s;
+    }
+  } else {
+    if (c.type == "NormalizeComponent") c.kind = AMLIKE_NORMALIZE;
+    else if (c.type == "SoftmaxComponent") c.kind = AMLIKE_SOFTMAX;
+    else if (c.type == "SigmoidComponent") c.kind = AMLIKE_SIGMOID;
+    else if (c.type == "TanhComponent") c.kind = AMLIKE_TANH;
+    else if (c.type == "RectifiedLinearComponent") c.kind = AMLIKE_RELU;
+    else KALDI_AMD_ERR("Unknown component type " << c.type);
+    ReadNonlinear(is, binary, &c);
+  }
+  return c;
+}
+
+void Nnet::Read(std::istream &is, bool binary) {  // nnet2/nnet-nnet.cc:89-103
+  components_.clear();
+  ExpectToken(is, binary, "<Nnet>");
+  int32 num_components;
+  ExpectToken(is, binary, "<NumComponents>");
+  ReadBasicType(is, binary, &num_components);
+  ExpectToken(is, binary, "<Components>");
+  if (num_components <= 0) KaldiErr("Nnet::Read, no components");
+  for (int32 c = 0; c < num_components; ++c) components_.push_back(ReadComponent(is, binary));
+  ExpectToken(is, binary, "</Components>");
+  ExpectToken(is, binary, "</Nnet>");
+  for (int32 c = 0; c + 1 < num_components; ++c)  // Nnet::Check
+    if (components_[c].output_dim != components_[c + 1].input_dim)
+      KALDI_AMD_ERR("Dimension mismatch between components " << c << " and " << c + 1);
+}
+
+int32 Nnet::LeftContext() const {
+  int32 ans = 0;
+  for (const Component &c : components_) ans += c.left_context;
+  return ans;
+}
+int32 Nnet::RightContext() const {
+  int32 ans = 0;
+  for (const Component &c : components_) ans += c.right_context;
+  return ans;
+}
+
+void AmNnet::Read(std::istream &is, bool binary) {  // nnet2/am-nnet.cc:39-42
+  nnet_.Read(is, binary);
+  priors_.Read(is, binary);
+  engine_.reset();
+}
+
+amlike_nnet_t *AmNnet::Engine() const {
+  if (!engine_) {
+    const int32 n = nnet_.NumComponents();
+    std::vector<amlike_component_t> comps(n);
+    std::vector<std::vector<float>> dense(n);
+    for (int32 i = 0; i < n; ++i) {
+      const Component &c = nnet_.GetComponent(i);
+      amlike_component_t &a = comps[i];
+      a.kind = c.kind;
+      a.input_dim = c.input_dim;
+      a.output_dim = c.output_dim;
+      a.left_context = c.left_context;
+      a.right_context = c.right_context;
+      a.const_dim = c.const_dim;
+      a.p = c.p;
+      a.linear = nullptr;
+      a.bias = nullptr;
+      a.sizes = nullptr;
+      if (c.kind == AMLIKE_AFFINE) {
+        dense[i].resize(static_cast<size_t>(c.output_dim) * c.input_dim);
+        for (int32 r = 0; r < c.output_dim; ++r)
+          std::copy(c.linear.RowData(r), c.linear.RowData(r) + c.input_dim,
+                    dense[i].begin() + static_cast<size_t>(r) * c.input_dim);
+        a.linear = dense[i].data();
+        a.bias = c.bias.Data();
+      } else if (c.kind == AMLIKE_SUMGROUP) {
+        a.sizes = c.sizes.data();
+      }
+    }
+    amlike_nnet_t *h = nullptr;
+    CheckAmlike(amlike_nnet_create(comps.data(), n, priors_.Dim() ? priors_.Data() : nullptr, priors_.Dim(), &h));
+    engine_.reset(h);
+  }
+  return engine_.get();
+}
+
+void NnetComputation(const AmNnet &am, const Matrix &feats, bool pad_input, int mode,
+                     BaseFloat prob_scale, Matrix *output) {
+  const Nnet &nnet = am.GetNnet();
+  if (feats.NumCols() != nnet.InputDim())
+    KALDI_AMD_ERR("Feature dimension is " << feats.NumCols() << " but network expects " << nnet.InputDim());
+  int32 rows = feats.NumRows();
+  if (!pad_input) rows -= nnet.LeftContext() + nnet.RightContext();
+  if (rows <= 0) KaldiErr("NnetComputation: output would be empty");
+  output->Resize(rows, nnet.OutputDim());
+  CheckAmlike(amlike_nnet_compute(am.Engine(), feats.Data(), feats.NumRows(), feats.Stride(), pad_input ? 1 : 0,
+                                  mode, prob_scale, output->Data(), output->Stride()));
+}
+
+void NnetComputation(const AmNnet &am, const Matrix &feats, bool pad_input, Matrix *output) {
+  NnetComputation(am, feats, pad_input, AMLIKE_NNET_POSTERIORS, 1.0f, output);
+}
+
+DecodableAmNnet::DecodableAmNnet(const TransitionModel &trans_model, const AmNnet &am_nnet,
+                                 const Matrix &feats, bool pad_input, BaseFloat prob_scale)
+    : trans_model_(trans_model) {
+  const Nnet &nnet = am_nnet.GetNnet();
+  const int32 rows = feats.NumRows() - (pad_input ? 0 : nnet.LeftContext() + nnet.RightContext());
+  if (rows <= 0) return;  // the reference warns and leaves the object empty
+  if (am_nnet.Priors().Dim() != trans_model.NumPdfs()) KaldiErr("Priors in neural network not set up.");
+  NnetComputation(am_nnet, feats, pad_input, AMLIKE_NNET_LOGLIKES, prob_scale, &log_probs_);
+}
+
+}  // namespace nnet2
+}  // namespace kaldi_amd

@@ -1,0 +1,94 @@
+// Host-side mirror of the reference's nnet2 forward classes, GPU-backed
+// (paths relative to /root/reference/src):
+//   nnet2/nnet-nnet.h:62-, nnet2/nnet-nnet.cc:89-103     Nnet (Read, dims, contexts)
+//   nnet2/nnet-component.cc:33-43, Read() of each type     Component::ReadNew
+//   nnet2/am-nnet.cc:31-42                                 AmNnet = Nnet + priors
+//   nnet2/nnet-compute.h:44-47                             NnetComputation()
+//   nnet2/decodable-am-nnet.h:37-98                        DecodableAmNnet
+// Only what the forward pass needs is kept from each component (the training-side
+// fields are parsed and dropped).
+#ifndef KALDI_AMD_CSRC_HOST_NNET_MODEL_H_
+#define KALDI_AMD_CSRC_HOST_NNET_MODEL_H_
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/amlike.h"
+#include "gmm_model.h"
+#include "kaldi_io.h"
+
+namespace kaldi_amd {
+namespace nnet2 {
+
+struct Component {
+  std::string type;  // e.g. "AffineComponentPreconditionedOnline"
+  int32 kind = 0;    // enum amlike_component_kind
+  int32 input_dim = 0, output_dim = 0;
+  int32 left_context = 0, right_context = 0, const_dim = 0;
+  float p = 2.0f;
+  Matrix linear;  // [output_dim x input_dim]
+  Vector bias;
+  std::vector<int32> sizes;
+};
+
+class Nnet {
+ public:
+  void Read(std::istream &is, bool binary);
+  int32 NumComponents() const { return static_cast<int32>(components_.size()); }
+  const Component &GetComponent(int32 c) const { return components_[c]; }
+  int32 InputDim() const { return components_.empty() ? 0 : components_.front().input_dim; }
+  int32 OutputDim() const { return components_.empty() ? 0 : components_.back().output_dim; }
+  int32 LeftContext() const;
+  int32 RightContext() const;
+
+ private:
+  std::vector<Component> components_;
+};
+
+class AmNnet {
+ public:
+  void Read(std::istream &is, bool binary);
+  const Nnet &GetNnet() const { return nnet_; }
+  const Vector &Priors() const { return priors_; }
+  int32 NumPdfs() const { return nnet_.OutputDim(); }
+  amlike_nnet_t *Engine() const;  // device-resident pipeline, created on first use
+
+ private:
+  Nnet nnet_;
+  Vector priors_;
+  struct EngineDeleter {
+    void operator()(amlike_nnet_t *n) const { amlike_nnet_destroy(n); }
+  };
+  mutable std::unique_ptr<amlike_nnet_t, EngineDeleter> engine_;
+};
+
+// nnet2/nnet-compute.h:44-47: output is resized to
+// [feats.NumRows() (- left - right context if !pad_input)] x OutputDim().
+void NnetComputation(const AmNnet &am_nnet, const Matrix &feats, bool pad_input, Matrix *output);
+// The same plus the output post-processing modes of include/amlike.h
+// (AMLIKE_NNET_LOG: nnet-am-compute --apply-log; AMLIKE_NNET_LOGLIKES: DecodableAmNnet).
+void NnetComputation(const AmNnet &am_nnet, const Matrix &feats, bool pad_input, int mode,
+                     BaseFloat prob_scale, Matrix *output);
+
+// nnet2/decodable-am-nnet.h:37-98.
+class DecodableAmNnet : public DecodableInterface {
+ public:
+  DecodableAmNnet(const TransitionModel &trans_model, const AmNnet &am_nnet, const Matrix &feats,
+                  bool pad_input = true, BaseFloat prob_scale = 1.0);
+  BaseFloat LogLikelihood(int32 frame, int32 transition_id) override {
+    return log_probs_(frame, trans_model_.TransitionIdToPdf(transition_id));
+  }
+  int32 NumFramesReady() const override { return log_probs_.NumRows(); }
+  int32 NumIndices() const override { return trans_model_.NumTransitionIds(); }
+  bool IsLastFrame(int32 frame) const override { return frame == NumFramesReady() - 1; }
+
+ private:
+  const TransitionModel &trans_model_;
+  Matrix log_probs_;
+};
+
+}  // namespace nnet2
+}  // namespace kaldi_amd
+
+#endif  // KALDI_AMD_CSRC_HOST_NNET_MODEL_H_

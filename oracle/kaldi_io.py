@@ -215,6 +215,36 @@ class Reader:
             return np.zeros((0, 0), dtype=np.float32)
         return np.array(rows, dtype=np.float32)
 
+    def diag_gmm(self, binary):
+        """gmm/diag-gmm.cc:722-767 (gconsts optional)."""
+        tok = self.token()
+        if tok not in ("<DiagGMM>", "<DiagGMMBegin>"):
+            raise ValueError("expected <DiagGMM> got %s" % tok)
+        out = {}
+        tok = self.token()
+        if tok == "<GCONSTS>":
+            out["gconsts"] = self.vector(binary)
+            tok = self.token()
+        if tok != "<WEIGHTS>":
+            raise ValueError("expected <WEIGHTS> got %s" % tok)
+        out["weights"] = self.vector(binary)
+        self.expect("<MEANS_INVVARS>")
+        out["means_invvars"] = self.matrix(binary)
+        self.expect("<INV_VARS>")
+        out["inv_vars"] = self.matrix(binary)
+        tok = self.token()
+        if tok not in ("</DiagGMM>", "<DiagGMMEnd>"):
+            raise ValueError("expected </DiagGMM> got %s" % tok)
+        return out
+
+    def am_diag_gmm(self, binary):
+        """gmm/am-diag-gmm.cc:147-161.  Returns (dim, [pdf dicts])."""
+        self.expect("<DIMENSION>")
+        dim = self.int32(binary)
+        self.expect("<NUMPDFS>")
+        n = self.int32(binary)
+        return dim, [self.diag_gmm(binary) for _ in range(n)]
+
     def skip_spaces_only(self):
         while self.p < len(self.d) and self.d[self.p:self.p + 1] in b" \t\r":
             self.p += 1

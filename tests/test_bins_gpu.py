@@ -1,0 +1,173 @@
+"""The command-line drop-ins (gmm-compute-likes, nnet-am-compute) and the Decodable
+shims, run as separate processes on the GPU and checked against the oracle on the
+same files.  Tolerance: 1e-3 absolute per (frame, pdf) log-likelihood."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import kaldi_io as kio
+from kaldi_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "kaldi_amd", "csrc", "bin")
+TOL = 1e-3
+
+
+def run(name, *args, ok=True):
+    p = subprocess.run([os.path.join(BIN, name), *args], capture_output=True, timeout=300)
+    if ok:
+        assert p.returncode == 0, p.stderr.decode()
+    return p
+
+
+def pdf_list(model):
+    off = model["pdf_offsets"]
+    return [dict(weights=model["weights"][a:b], means_invvars=model["means_invvars"][a:b],
+                 inv_vars=model["inv_vars"][a:b]) for a, b in zip(off[:-1], off[1:])]
+
+
+def write_gmm_mdl(path, model, binary=True):
+    P = len(model["pdf_offsets"]) - 1
+    with kio.open_out(path, binary) as f:
+        topo, triples = kio.make_transition_model(P)
+        tid2pdf = kio.write_transition_model(f, binary, topo, triples)
+        kio.write_am_diag_gmm(f, binary, model["dim"], pdf_list(model), with_gconsts=False)
+    return tid2pdf
+
+
+def oracle_gmm(model, feats, prune=-1.0):
+    gc = np.concatenate([oracle.compute_gconsts(p["weights"], p["means_invvars"], p["inv_vars"])[0]
+                         for p in pdf_list(model)])
+    out, st = oracle.gmm_compute_likes(gc, model["means_invvars"], model["inv_vars"],
+                                       model["pdf_offsets"], feats, prune)
+    assert st == 0
+    return out
+
+
+@pytest.fixture(scope="module")
+def gmm_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("gmm")
+    model = synth.make_gmm(39, 120, 900, seed=21)
+    tid2pdf = write_gmm_mdl(str(d / "final.mdl"), model)
+    lens = [1, 37, 412, 64, 1000]
+    feats = [synth.make_feats(model, n, seed=30 + i) for i, n in enumerate(lens)]
+    items = [("utt%02d" % i, f) for i, f in enumerate(feats)]
+    kio.write_ark(str(d / "feats.ark"), items)
+    return d, model, items, tid2pdf
+
+
+@pytest.mark.parametrize("fpb", ["32768", "100", "1"])
+def test_gmm_compute_likes_binary(gmm_files, fpb):
+    d, model, items, _ = gmm_files
+    out = str(d / ("likes_%s.ark" % fpb))
+    p = run("gmm-compute-likes", "--frames-per-batch=" + fpb, str(d / "final.mdl"),
+            "ark:" + str(d / "feats.ark"), "ark:" + out)
+    assert b"computed likelihoods for 5 utterances" in p.stderr
+    got = kio.read_ark(out)
+    assert [k for k, _ in got] == [k for k, _ in items]
+    for (_, f), (_, l) in zip(items, got):
+        want = oracle_gmm(model, f)
+        assert l.shape == want.shape
+        assert np.abs(l - want).max() <= TOL
+        assert (l.argmax(1) == want.argmax(1)).mean() >= 0.9999
+
+
+def test_gmm_compute_likes_text_model_and_text_output(gmm_files, tmp_path):
+    d, model, items, _ = gmm_files
+    small = synth.make_gmm(13, 9, 40, seed=22)
+    write_gmm_mdl(str(tmp_path / "t.mdl"), small, binary=False)
+    feats = synth.make_feats(small, 50, seed=5)
+    kio.write_ark(str(tmp_path / "f.ark"), [("a", feats)], binary=False)
+    out = str(tmp_path / "o.ark")
+    run("gmm-compute-likes", str(tmp_path / "t.mdl"), "ark:" + str(tmp_path / "f.ark"), "ark,t:" + out)
+    (key, l), = kio.read_ark(out)
+    # the text model carries ~7 significant digits, so compare against what was read back
+    r = kio.Reader(open(str(tmp_path / "t.mdl"), "rb").read())
+    txt = open(str(tmp_path / "t.mdl"), "rb").read()
+    r = kio.Reader(txt, txt.index(b"<DIMENSION>"))
+    dim, pdfs = r.am_diag_gmm(False)
+    back = dict(small)
+    back["weights"] = np.concatenate([p["weights"] for p in pdfs])
+    back["means_invvars"] = np.concatenate([p["means_invvars"] for p in pdfs])
+    back["inv_vars"] = np.concatenate([p["inv_vars"] for p in pdfs])
+    feats_back = kio.read_ark(str(tmp_path / "f.ark"))[0][1]
+    want = oracle_gmm(back, feats_back)
+    assert key == "a" and np.abs(l - want).max() <= TOL
+
+
+def test_gmm_compute_likes_dim_mismatch_fails(gmm_files, tmp_path):
+    d, model, _, _ = gmm_files
+    kio.write_ark(str(tmp_path / "f.ark"), [("a", np.zeros((3, 40), np.float32))])
+    p = run("gmm-compute-likes", str(d / "final.mdl"), "ark:" + str(tmp_path / "f.ark"),
+            "ark:" + str(tmp_path / "o.ark"), ok=False)
+    assert p.returncode != 0 and b"mismatch" in p.stderr.lower()
+
+
+def test_decodable_gmm_scaled_and_unmapped(gmm_files):
+    d, model, items, tid2pdf = gmm_files
+    out = str(d / "dec.ark")
+    run("amlike-decodable", "--acoustic-scale=0.0833", "gmm-scaled", str(d / "final.mdl"),
+        "ark:" + str(d / "feats.ark"), "ark:" + out)
+    got = kio.read_ark(out)
+    for (_, f), (_, l) in zip(items, got):
+        want = np.float32(0.0833) * oracle_gmm(model, f)[:, tid2pdf[1:]]
+        assert l.shape == want.shape and np.abs(l - want).max() <= TOL
+    run("amlike-decodable", "gmm-unmapped", str(d / "final.mdl"),
+        "ark:" + str(d / "feats.ark"), "ark:" + out)
+    got = kio.read_ark(out)
+    for (_, f), (_, l) in zip(items, got):
+        want = oracle_gmm(model, f)
+        assert l.shape == want.shape and np.abs(l - want).max() <= TOL
+
+
+@pytest.fixture(scope="module")
+def nnet_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("nnet")
+    comps, priors = synth.make_pnorm_nnet(input_dim=40, left=4, right=4, hidden=200, pnorm_out=40,
+                                          num_hidden=2, num_pdfs=150, mix_up=170, seed=41)
+    with kio.open_out(str(d / "final.mdl"), True) as f:
+        topo, triples = kio.make_transition_model(150)
+        tid2pdf = kio.write_transition_model(f, True, topo, triples)
+        kio.write_am_nnet(f, True, comps, priors)
+    rng = np.random.default_rng(42)
+    items = [("u%d" % i, rng.standard_normal((n, 40)).astype(np.float32))
+             for i, n in enumerate([5, 9, 300, 77])]
+    kio.write_ark(str(d / "feats.ark"), items)
+    return d, comps, priors, items, tid2pdf
+
+
+@pytest.mark.parametrize("apply_log", [False, True])
+@pytest.mark.parametrize("pad", [True, False])
+def test_nnet_am_compute_binary(nnet_files, apply_log, pad):
+    d, comps, priors, items, _ = nnet_files
+    out = str(d / ("o_%d_%d.ark" % (apply_log, pad)))
+    run("nnet-am-compute", "--apply-log=%s" % str(apply_log).lower(), "--pad-input=%s" % str(pad).lower(),
+        str(d / "final.mdl"), "ark:" + str(d / "feats.ark"), "ark:" + out)
+    got = dict(kio.read_ark(out))
+    for key, f in items:
+        if not pad and f.shape[0] <= 8:
+            assert key not in got  # skipped: output would be empty
+            continue
+        want = oracle.nnet_compute(comps, priors, f, pad_input=pad, mode=1 if apply_log else 0)
+        l = got[key]
+        assert l.shape == want.shape
+        if apply_log:
+            assert np.abs(l - want).max() <= TOL
+        else:
+            assert np.abs(l - want).max() <= 1e-5
+            assert (l.argmax(1) == want.argmax(1)).mean() >= 0.9999
+
+
+def test_decodable_am_nnet(nnet_files):
+    d, comps, priors, items, tid2pdf = nnet_files
+    out = str(d / "dec.ark")
+    run("amlike-decodable", "--acoustic-scale=0.1", "nnet", str(d / "final.mdl"),
+        "ark:" + str(d / "feats.ark"), "ark:" + out)
+    got = kio.read_ark(out)
+    for (_, f), (_, l) in zip(items, got):
+        want = oracle.nnet_compute(comps, priors, f, pad_input=True, mode=2, prob_scale=0.1)[:, tid2pdf[1:]]
+        assert l.shape == want.shape and np.abs(l - want).max() <= TOL
