@@ -635,6 +635,33 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Pruned log-sum-exp over each pdf's Gaussians (VectorBase::LogSumExp with prune > 0,
+// /root/reference/src/matrix/kaldi-vector.cc:1060-1080): the maximum is found first, then
+// only terms f >= max(max + log(FLT_EPSILON), max - prune) are summed.  One thread per
+// (frame, pdf); scores is [T x ld] with the pdf's Gaussians in columns offsets[p]..offsets[p+1]-1.
+__global__ void __launch_bounds__(256)
+    gmm_pruned_lse_kernel(const float *__restrict__ scores, int ld,
+                          const int32_t *__restrict__ offsets, int num_pdfs, int T, float prune,
+                          float *__restrict__ out, int ldo, int *flag) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (p >= num_pdfs || t >= T) return;
+  const float *row = scores + (size_t)t * ld;
+  const int g0 = offsets[p], g1 = offsets[p + 1];
+  float mx = -INFINITY;
+  for (int g = g0; g < g1; ++g) mx = fmaxf(mx, row[g]);
+  float cutoff = mx + (-15.9423847198486328125f);  // logf(FLT_EPSILON)
+  if (mx - prune > cutoff) cutoff = mx - prune;
+  float sum = 0.0f;
+  for (int g = g0; g < g1; ++g) {
+    const float f = row[g];
+    if (f >= cutoff) sum += __expf(f - mx);
+  }
+  const float v = mx + __logf(sum);
+  out[(size_t)t * ldo + p] = v;
+  if (!(fabsf(v) <= kMaxAbsLogLike)) atomicOr(flag, 1);
+}
+
 // ---------------------------------------------------------------------------
 // Host side: the packed model.
 
@@ -697,9 +724,10 @@ struct amlike_gmm {
   SplitPdf *d_splits = nullptr;
   float *d_gconsts = nullptr, *d_miv = nullptr, *d_iv = nullptr;  // flat copies [G], [G x dim]
   int *d_flag = nullptr;
+  int32_t *d_offsets = nullptr;  // [num_pdfs + 1]
   std::vector<int32_t> pdf_offsets;
   hipStream_t stream = nullptr;  // used by the host-pointer entry points
-  DeviceBuffer ws_feats, ws_out, ws_part, ws_pad, ws_expand;
+  DeviceBuffer ws_feats, ws_out, ws_part, ws_pad, ws_expand, ws_gauss;
   std::mutex mu;
   std::string info;
 };
@@ -1069,6 +1097,16 @@ int amlike_gmm_create(const float *gconsts, const float *means_invvars, const fl
     rc = up(&g->d_gconsts, gconsts, (size_t)num_gauss);
     if (rc == AMLIKE_OK) rc = up(&g->d_miv, means_invvars, (size_t)num_gauss * dim);
     if (rc == AMLIKE_OK) rc = up(&g->d_iv, inv_vars, (size_t)num_gauss * dim);
+    if (rc == AMLIKE_OK) {
+      hipError_t e = hipMalloc(&g->d_offsets, (size_t)(num_pdfs + 1) * sizeof(int32_t));
+      if (e == hipSuccess)
+        e = hipMemcpy(g->d_offsets, pdf_offsets, (size_t)(num_pdfs + 1) * sizeof(int32_t),
+                      hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        SetError("amlike_gmm_create: %s", hipGetErrorString(e));
+        rc = AMLIKE_EHIP;
+      }
+    }
   }
   if (rc == AMLIKE_OK) {
     hipError_t e = hipMalloc(&g->d_flag, sizeof(int));
@@ -1098,6 +1136,8 @@ int amlike_gmm_destroy(amlike_gmm_t *g) {
   (void)hipFree(g->d_miv);
   (void)hipFree(g->d_iv);
   (void)hipFree(g->d_flag);
+  (void)hipFree(g->d_offsets);
+  g->ws_gauss.Free();
   g->ws_feats.Free();
   g->ws_out.Free();
   g->ws_part.Free();
@@ -1118,11 +1158,28 @@ int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32
                          void *stream) {
   int rc = CheckScoreArgs(g, T, ld, feat_dim, ldo, d_feats, d_out);
   if (rc != AMLIKE_OK) return rc;
-  if (log_sum_exp_prune > 0.0f) {
-    SetError("amlike_gmm_score: log_sum_exp_prune > 0 is not available in this build");
-    return AMLIKE_EINVAL;
-  }
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (log_sum_exp_prune > 0.0f) {
+    // Pruning needs each pdf's maximum before its sum, so this mode goes through the
+    // per-Gaussian scores, in frame chunks that keep the scratch matrix near 1 GiB.
+    const int G = g->num_gauss;
+    const int chunk = std::max(64, (int)std::min<size_t>((size_t)T, ((size_t)1 << 28) / (size_t)G));
+    rc = g->ws_gauss.Reserve((size_t)std::min(chunk, T) * G * sizeof(float));
+    if (rc != AMLIKE_OK) return rc;
+    float *scores = static_cast<float *>(g->ws_gauss.ptr);
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+      const int tn = std::min(chunk, T - t0);
+      rc = amlike_gmm_gauss_loglikes_dev(g, 0, g->num_pdfs, d_feats + (size_t)t0 * ld, tn, ld,
+                                         feat_dim, scores, G, stream);
+      if (rc != AMLIKE_OK) return rc;
+      hipLaunchKernelGGL(gmm_pruned_lse_kernel, dim3((g->num_pdfs + 255) / 256, tn), dim3(256), 0, st,
+                         scores, G, g->d_offsets, g->num_pdfs, tn, log_sum_exp_prune,
+                         d_out + (size_t)t0 * ldo, ldo, g->d_flag);
+      AMLIKE_HIP(hipGetLastError());
+    }
+    g->info = "pruned log-sum-exp over per-Gaussian scores";
+    return AMLIKE_OK;
+  }
   const float *use = d_feats;
   int use_ld = ld;
   if (g->variant->mode == 0) {  // the fp32 kernel reads rows as float4

@@ -176,3 +176,30 @@ def test_rm_tri1_shape_full_parity(amlike_device):
     feats = synth.make_feats(m, 2000, seed=778)
     am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
     _check(m, feats, am.LogLikelihoods(feats))
+
+
+@pytest.mark.parametrize("prune", [2.0, 5.0, 30.0])
+def test_log_sum_exp_prune(amlike_device, prune):
+    """DecodableAmDiagGmmUnmapped's log_sum_exp_prune (gmm/decodable-am-diag-gmm.cc:64):
+    terms below max - prune are dropped.  A Gaussian whose score lies within rounding
+    of the cutoff may fall on either side, so entries that differ must have one."""
+    m = synth.make_gmm(40, 60, 1500, seed=91)
+    feats = synth.make_feats(m, 200, seed=92)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    got = am.LogLikelihoods(feats, log_sum_exp_prune=prune)
+    assert "pruned" in am.kernel_info()
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    want, st = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"],
+                                        feats, prune=prune)
+    assert st == 0
+    unpruned, _ = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"], feats)
+    if prune < 10:
+        assert np.abs(want - unpruned).max() > 10 * TOL  # the pruning is visible at this setting
+    bad = np.abs(got - want) >= TOL
+    assert bad.mean() < 1e-3
+    per_gauss = oracle.diag_gmm_loglikes_mat(gc, m["means_invvars"], m["inv_vars"], feats)
+    off = m["pdf_offsets"]
+    for t, p in zip(*np.nonzero(bad)):
+        f = per_gauss[t, off[p]:off[p + 1]]
+        cutoff = f.max() - prune
+        assert np.abs(f - cutoff).min() < 1e-3, "entry (%d,%d) differs away from the cutoff" % (t, p)
