@@ -34,24 +34,13 @@ import numpy as np
 import torch
 
 from kaldi_amd import _lib, gmm, synth
+from kaldi_amd.sharding import reduce_summary, shard_utterances
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
 # The shipped kernel forms every fp32-grade product from 6 bf16 partial products
 # (bf16x3 split of both operands), so the matrix pipe bounds it at peak / 6.
 BF16X3_PRODUCTS = 6
-
-
-def shard_utterances(lengths, world):
-    """Longest-processing-time-first assignment of utterances to ranks."""
-    order = np.argsort(-lengths, kind="stable")
-    load = np.zeros(world, dtype=np.int64)
-    owner = np.empty(len(lengths), dtype=np.int64)
-    for i in order:
-        r = int(np.argmin(load))
-        owner[i] = r
-        load[r] += lengths[i]
-    return owner
 
 
 def cpu_baseline_gmm(model, gconsts, dim, seconds_target=15.0):
@@ -149,15 +138,8 @@ def main():
     am.Poll(stream)  # raises if any log-likelihood was NaN/Inf
 
     # Summary statistics, all-reduced like the reference binaries' totals.
-    stats = torch.stack([d_out.max(dim=1).values.double().sum(),
-                         torch.tensor(float(T), dtype=torch.float64, device=dev),
-                         torch.tensor(elapsed, dtype=torch.float64, device=dev)])
-    if dist is not None:
-        tmax = stats[2:3].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats[:2], op=dist.ReduceOp.SUM)
-        elapsed = float(tmax.item())
-    tot_like, tot_frames = float(stats[0].item()), float(stats[1].item())
+    (tot_like, tot_frames), elapsed = reduce_summary(
+        dist, [d_out.max(dim=1).values.double().sum().item(), float(T)], elapsed, device=dev)
 
     # Dominant kernel, timed live with HIP events on the launch stream.
     ms = am.TimeScoreDevice(d_feats.data_ptr(), T, ldp, D, d_out.data_ptr(), P, 10, stream)

@@ -6,7 +6,7 @@ to read back what the product and the reference driver write.  The product's
 own readers and writers are C++ (kaldi_amd/csrc/host/); nothing here is
 imported by the product.
 
-Pinned: tests/test_oracle_vs_ref.py round-trips every writer here through the
+Pinned: tests/test_oracle_cpu.py round-trips every writer here through the
 real reference library's Read/Write (oracle/_ref/ref_driver *-copy), except the
 TransitionModel/Topology writer, which the reference build cannot cover
 (hmm/transition-model.h needs an OpenFst header the image lacks): that one is
@@ -214,6 +214,92 @@ class Reader:
         if not rows:
             return np.zeros((0, 0), dtype=np.float32)
         return np.array(rows, dtype=np.float32)
+
+    def bool_(self, binary):
+        self.skip_ws() if not binary else None
+        c = self.d[self.p:self.p + 1]
+        self.p += 1 if binary else 2
+        return c == b"T"
+
+    def int_vector(self, binary):
+        if binary:
+            sz, n = struct.unpack_from("<bi", self.d, self.p)
+            assert sz == 4
+            self.p += 5
+            a = np.frombuffer(self.d, dtype="<i4", count=n, offset=self.p)
+            self.p += 4 * n
+            return a.astype(np.int32)
+        self.expect("[")
+        vals = []
+        while True:
+            t = self.token()
+            if t == "]":
+                break
+            vals.append(int(t))
+        return np.array(vals, dtype=np.int32)
+
+    def component(self, binary):
+        """Read() of each component type in nnet2/nnet-component.cc, keeping what the
+        forward pass needs; returns the dict form write_component() takes."""
+        t = self.token()[1:-1]
+        c = {"type": t}
+        if t == "SpliceComponent":
+            self.expect("<InputDim>"); c["input_dim"] = self.int32(binary)
+            tok = self.token()
+            if tok == "<LeftContext>":
+                c["left"] = self.int32(binary)
+                self.expect("<RightContext>"); c["right"] = self.int32(binary)
+            else:
+                raise ValueError("SpliceComponent <Context> form is not used here")
+            self.expect("<ConstComponentDim>"); c["const_dim"] = self.int32(binary)
+            self.expect("</SpliceComponent>")
+        elif t == "FixedAffineComponent":
+            self.expect("<LinearParams>"); c["linear"] = self.matrix(binary)
+            self.expect("<BiasParams>"); c["bias"] = self.vector(binary)
+            self.expect("</FixedAffineComponent>")
+        elif t in ("AffineComponent", "AffineComponentPreconditioned", "AffineComponentPreconditionedOnline"):
+            self.expect("<LearningRate>"); c["lr"] = self.float32(binary)
+            self.expect("<LinearParams>"); c["linear"] = self.matrix(binary)
+            self.expect("<BiasParams>"); c["bias"] = self.vector(binary)
+            while True:  # training-side fields up to the closing token
+                tok = self.token()
+                if tok == "</%s>" % t:
+                    break
+                if tok == "<IsGradient>":
+                    self.bool_(binary)
+                elif tok in ("<RankIn>", "<RankOut>", "<UpdatePeriod>", "<Rank>"):
+                    self.int32(binary)
+                else:
+                    self.float32(binary)
+        elif t == "PnormComponent":
+            self.expect("<InputDim>"); c["input_dim"] = self.int32(binary)
+            self.expect("<OutputDim>"); c["output_dim"] = self.int32(binary)
+            self.expect("<P>"); c["p"] = self.float32(binary)
+            self.expect("</PnormComponent>")
+        elif t in ("NormalizeComponent", "SoftmaxComponent", "SigmoidComponent", "TanhComponent",
+                   "RectifiedLinearComponent"):
+            self.expect("<Dim>"); c["dim"] = self.int32(binary)
+            self.expect("<ValueSum>"); self.vector(binary)
+            self.expect("<DerivSum>"); self.vector(binary)
+            self.expect("<Count>"); self.float32(binary)
+            self.expect("</%s>" % t)
+        elif t == "SumGroupComponent":
+            self.expect("<Sizes>"); c["sizes"] = [int(x) for x in self.int_vector(binary)]
+            self.expect("<SumGroupComponent>")
+        else:
+            raise ValueError("component type %s" % t)
+        return c
+
+    def am_nnet(self, binary):
+        """nnet2/nnet-nnet.cc:89-103 then nnet2/am-nnet.cc:39-42.  Returns (components, priors)."""
+        self.expect("<Nnet>")
+        self.expect("<NumComponents>")
+        n = self.int32(binary)
+        self.expect("<Components>")
+        comps = [self.component(binary) for _ in range(n)]
+        self.expect("</Components>")
+        self.expect("</Nnet>")
+        return comps, self.vector(binary)
 
     def diag_gmm(self, binary):
         """gmm/diag-gmm.cc:722-767 (gconsts optional)."""

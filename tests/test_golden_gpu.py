@@ -1,0 +1,80 @@
+"""The HIP path against the committed golden vectors: outputs of the real reference
+library (tests/golden/make_golden.py), so these run on the GPU box where the reference
+itself is absent.  Tolerance 1e-3 absolute on log-likelihoods, 1e-5 on posteriors."""
+import numpy as np
+import pytest
+
+from kaldi_amd import gmm, nnet
+from golden_util import load_am_gmm, load_am_nnet, load_ark, load_vec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", ["gmm_a", "gmm_b"])
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_gmm_likes_vs_golden(amlike_device, tag, mode, monkeypatch):
+    m = load_am_gmm(tag + ".mdl")
+    if mode == "f32" and m["dim"] not in (39, 40):
+        pytest.skip("the exact-fp32 kernel is built for dims 39 and 40")
+    monkeypatch.setenv("AMLIKE_GMM_MODE", mode)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    want = dict(load_ark(tag + "_likes.ark"))
+    for key, feats in load_ark(tag + "_feats.ark"):
+        got = am.LogLikelihoods(feats)
+        assert got.shape == want[key].shape
+        assert np.abs(got - want[key]).max() <= 1e-3
+        assert (got.argmax(1) == want[key].argmax(1)).all()
+
+
+def test_gmm_gconsts_vs_golden_bits(amlike_device):
+    for tag in ("gmm_a", "gmm_b"):
+        m = load_am_gmm(tag + ".mdl")
+        am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+        np.testing.assert_array_equal(np.asarray(am.gconsts).view(np.uint32),
+                                      load_vec(tag + "_gconsts.vec").view(np.uint32))
+
+
+def test_gmm_pruned_vs_golden(amlike_device):
+    m = load_am_gmm("gmm_a.mdl")
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    want = dict(load_ark("gmm_a_likes_prune5.ark"))
+    for key, feats in load_ark("gmm_a_feats.ark"):
+        got = am.LogLikelihoods(feats, log_sum_exp_prune=5.0)
+        # a Gaussian within rounding of the cutoff may fall on either side
+        assert (np.abs(got - want[key]) <= 1e-3).mean() >= 0.999
+
+
+def test_per_gaussian_loglikes_vs_golden(amlike_device):
+    m = load_am_gmm("gmm_a.mdl")
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    want = dict(load_ark("gmm_a_pdf3_gauss.ark"))
+    for key, feats in load_ark("gmm_a_feats.ark"):
+        got = am.ComponentLogLikelihoods(feats, 3, 4)
+        assert got.shape == want[key].shape and np.abs(got - want[key]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("out,pad,mode,scale,tol", [
+    ("nnet_a_post.ark", True, nnet.POSTERIORS, 1.0, 1e-5), ("nnet_a_log.ark", True, nnet.LOG, 1.0, 1e-3),
+    ("nnet_a_loglikes.ark", True, nnet.LOGLIKES, 0.1, 1e-3),
+    ("nnet_a_post_nopad.ark", False, nnet.POSTERIORS, 1.0, 1e-5),
+])
+def test_nnet_vs_golden(amlike_device, out, pad, mode, scale, tol):
+    comps, priors = load_am_nnet("nnet_a.mdl")
+    net = nnet.AmNnet(comps, priors)
+    want = dict(load_ark(out))
+    for key, feats in load_ark("nnet_a_feats.ark"):
+        if key not in want:
+            continue
+        got = net.Compute(feats, pad_input=pad, mode=mode, prob_scale=scale)
+        assert got.shape == want[key].shape
+        assert np.abs(got - want[key]).max() <= tol
+        assert (got.argmax(1) == want[key].argmax(1)).all()
+
+
+def test_nnet_other_components_vs_golden(amlike_device):
+    comps, priors = load_am_nnet("nnet_b.mdl")
+    net = nnet.AmNnet(comps, priors)
+    want = dict(load_ark("nnet_b_post.ark"))
+    for key, feats in load_ark("nnet_b_feats.ark"):
+        got = net.Compute(feats, pad_input=True, mode=nnet.POSTERIORS)
+        assert np.abs(got - want[key]).max() <= 1e-5
