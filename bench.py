@@ -41,6 +41,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (v_mfma_f32_32x3
 # The shipped kernel forms every fp32-grade product from 6 bf16 partial products
 # (bf16x3 split of both operands), so the matrix pipe bounds it at peak / 6.
 BF16X3_PRODUCTS = 6
+# The default kernel uses fp16x2 operands (same matrix rate as bf16): 3 partial products.
+F16X2_PRODUCTS = 3
 
 
 def cpu_baseline_gmm(model, gconsts, dim, seconds_target=15.0):
@@ -145,7 +147,10 @@ def main():
     ms = am.TimeScoreDevice(d_feats.data_ptr(), T, ldp, D, d_out.data_ptr(), P, 10, stream)
     flop_per_frame = 2.0 * (2 * D + 1) * G
     achieved = flop_per_frame * T / (ms * 1e-3) / 1e12
-    if "bf16x3" in am.kernel_info():
+    if "f16x2" in am.kernel_info():
+        peak = BF16_MFMA_PEAK_TFLOPS / F16X2_PRODUCTS
+        peak_basis = "fp16 MFMA dense peak 2500 TFLOP/s / 3 fp16 partial products per fp32-grade product"
+    elif "bf16x3" in am.kernel_info():
         peak = BF16_MFMA_PEAK_TFLOPS / BF16X3_PRODUCTS
         peak_basis = "bf16 MFMA dense peak 2500 TFLOP/s / 6 bf16 partial products per fp32-grade product"
     else:

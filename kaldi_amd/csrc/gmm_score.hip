@@ -46,6 +46,7 @@ namespace amlike {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));  // 8 bf16 = one 32x32x16 operand
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));  // 8 fp16 = one 32x32x16 operand
 
 constexpr int kColDiscard = -1;       // segment whose result is dropped (padding chunks)
 constexpr float kNegInit = -3.0e38f;  // finite "minus infinity" for the running max
@@ -57,10 +58,18 @@ constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
 // bf16x3 kernel: feature tiles staged per block barrier (LDS: 2 groups x this x 15 KiB at D=40;
 // 8-wave blocks own a CU's LDS alone, 4-wave blocks share it two per CU).
-constexpr int FramesTilesPerBarrier(int waves, int ks) {
-  const int budget = waves == 8 ? 120 * 1024 : 60 * 1024, pair = 2 * ks * 3 * 64 * 16;
+constexpr int FramesTilesPerBarrier(int waves, int ks, int parts = 3) {
+  const int budget = waves == 8 ? 120 * 1024 : 60 * 1024, pair = 2 * ks * parts * 64 * 16;
   return budget / pair >= 4 ? 4 : budget / pair >= 2 ? 2 : 1;
 }
+// Reference-based log-sum-exp of the fast kernel: a segment's running sum is kept relative
+// to R = (score of its first Gaussian pair) + kRefShift in log2 units, so the first term
+// is 2^-kRefShift (a normal float) and later terms may exceed it by up to 2^227 before
+// the sum overflows; overflowed (frame, pdf) pairs are recomputed exactly afterwards.
+constexpr float kRefShift = 100.0f;
+// fp16x2 operands: scaled feature values beyond this magnitude send the launch to the
+// wide-range (bf16x3) kernel.
+constexpr float kF16Limit = 60000.0f;
 
 // Device view of the packed model (see PackModel below for the layout).
 struct GmmPackView {
@@ -83,7 +92,22 @@ struct ScoreArgs {
   float *part_m, *part_s;  // [num_partials x part_ld] for pdfs split over waves
   int part_ld;
   int *flag;  // set to 1 when a result is NaN/Inf
+  // Fast-path bookkeeping.  ctl[0]: number of (frame, pdf) pairs whose sum overflowed
+  // (listed in fix_list up to fix_cap); ctl[1]: nonzero when the features do not fit the
+  // fp16 operand range.  guard 0: always run; 1: run unless ctl[1]; 2: run only when the
+  // fast path could not finish (ctl[1] set, or more overflows than fix_cap).
+  int *ctl;
+  int2 *fix_list;
+  int fix_cap;
+  int guard;
 };
+
+__device__ __forceinline__ bool guard_skips(const int *ctl, int fix_cap, int guard) {
+  if (guard == 0) return false;
+  const int range = __builtin_nontemporal_load(ctl + 1), count = __builtin_nontemporal_load(ctl);
+  const bool fallback = range != 0 || count > fix_cap;
+  return guard == 1 ? range != 0 : !fallback;
+}
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
@@ -310,7 +334,9 @@ __global__ void __launch_bounds__(64 * W, (64 * W) / 256)
 template <int KS>
 __global__ void __launch_bounds__(256)
     gmm_expand_feats_kernel(const float *__restrict__ feats, int T, int ld, int dim,
-                            uint4 *__restrict__ bx, int num_ftiles) {
+                            uint4 *__restrict__ bx, int num_ftiles, const float *bscale, int *ctl,
+                            int fix_cap, int guard) {
+  if (guard_skips(ctl, fix_cap, guard)) return;
   const int idx = blockIdx.x * 256 + threadIdx.x;  // (ftile, s, lane)
   const int lane = idx & 63;
   const int s = (idx >> 6) % KS;
@@ -343,6 +369,46 @@ __global__ void __launch_bounds__(256)
   o[128] = pack(p3);
 }
 
+// fp16x2 operand image of the features for the fast kernel: [frame tile][KS][2 parts][64 lanes]
+// 8 x fp16.  Value k of a lane is x_d (h = 0) or x_d^2 (h = 1) times bscale[h][d], an exact
+// power of two chosen with the model (PackModel) so that both operands sit well inside the
+// fp16 range; x' = p1 + p2 to 22 bits.  A value outside the range sets ctl[1].
+template <int KS>
+__global__ void __launch_bounds__(256)
+    gmm_expand_feats_f16_kernel(const float *__restrict__ feats, int T, int ld, int dim,
+                                uint4 *__restrict__ bx, int num_ftiles,
+                                const float *__restrict__ bscale, int *ctl, int fix_cap, int guard) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (ftile, s, lane)
+  const int lane = idx & 63;
+  const int s = (idx >> 6) % KS;
+  const int ft = (idx >> 6) / KS;
+  if (ft >= num_ftiles) return;
+  const int j = lane & 31, h = lane >> 5;
+  const int t = ft * 32 + j;
+  unsigned short p1[8], p2[8];
+  bool out_of_range = false;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const int d = 8 * s + jj;
+    float x = (t < T && d < dim) ? feats[(size_t)t * ld + d] : 0.0f;
+    if (h) x = x * x;
+    x *= bscale[h * (KS * 8) + d];
+    out_of_range |= !(fabsf(x) <= kF16Limit);
+    const _Float16 h1 = static_cast<_Float16>(x);
+    const _Float16 h2 = static_cast<_Float16>(x - static_cast<float>(h1));
+    p1[jj] = __builtin_bit_cast(unsigned short, h1);
+    p2[jj] = __builtin_bit_cast(unsigned short, h2);
+  }
+  auto pack = [](const unsigned short *p) {
+    return make_uint4(p[0] | (unsigned)p[1] << 16, p[2] | (unsigned)p[3] << 16,
+                      p[4] | (unsigned)p[5] << 16, p[6] | (unsigned)p[7] << 16);
+  };
+  uint4 *o = bx + ((size_t)(ft * KS + s) * 2) * 64 + lane;
+  o[0] = pack(p1);
+  o[64] = pack(p2);
+  if (out_of_range) atomicOr(ctl + 1, 1);
+}
+
 // ABL (timing experiments only, never dispatched in production): bit0 no output
 // stores, bit1 no (max,sum) updates, bit2 no segment closing, bit3 no feature
 // fragment reads, bit4 no barrier / staging.
@@ -352,6 +418,7 @@ __global__ void __launch_bounds__(64 * W, OCC)
   constexpr int kTileU4 = KS * 3 * 64;  // uint4 per expanded 32-frame tile
   constexpr int FTB = FramesTilesPerBarrier(W, KS);
   static_assert(NT * 16 <= 64, "segment columns are held one per lane");
+  if (guard_skips(ar.ctl, ar.fix_cap, ar.guard)) return;
   int bx, by;
   {
     const int total = gridDim.x, L = blockIdx.x;
@@ -533,6 +600,261 @@ __global__ void __launch_bounds__(64 * W, OCC)
   if (bad) atomicOr(ar.flag, 1);
 }
 
+
+// ---------------------------------------------------------------------------
+// The fast scoring kernel.  Same structure as gmm_score_bf16x3_kernel above (model
+// operands stationary in registers, expanded features staged through LDS, matrix
+// instructions of frame tile k+1 interleaved with the log-sum-exp of tile k), with
+// two changes that halve the work per (Gaussian, frame):
+//
+//  PREC = 1: fp16x2 operands.  With 11 mantissa bits per fp16, value = p1 + p2 carries
+//    22 bits and the product needs three partial products (a2b1, a1b2, a1b1) instead
+//    of six; PackModel scales every k-row by a power of two so both operands stay in
+//    the fp16 range, and the feature prepass reports values that do not (the launch
+//    then falls back to the bf16x3 kernel, which has the fp32 exponent range).
+//    PREC = 0 keeps the bf16x3 operands.
+//
+//  The log-sum-exp of a pdf segment is taken relative to a reference fixed at the
+//    segment's first register, R = max(f of its first Gaussian in either half-wave)
+//    + kRefShift: per element that is v_sub, v_exp, v_add (16 issue cycles) instead of
+//    the 7-instruction running-maximum update (32).  PackModel puts each pdf's broadest
+//    Gaussians first, which makes an overflow of the sum (some Gaussian more than
+//    2^227 above the reference) a rare event; such (frame, pdf) pairs are appended to
+//    fix_list and recomputed exactly by gmm_fix_kernel.
+template <int KS, int NT, int W, int OCC, int PREC, int ABL = 0>
+__global__ void __launch_bounds__(64 * W, OCC)
+    gmm_score_fast_kernel(GmmPackView pk, ScoreArgs ar) {
+  constexpr int NP = PREC ? 2 : 3;    // parts per operand value
+  constexpr int NPROD = PREC ? 3 : 6; // partial products per k-step
+  constexpr int kTileU4 = KS * NP * 64;
+  constexpr int FTB = FramesTilesPerBarrier(W, KS, NP);
+  static_assert(NT * 16 <= 64, "segment columns are held one per lane");
+  if (guard_skips(ar.ctl, ar.fix_cap, ar.guard)) return;
+  int bx, by;
+  {
+    const int total = gridDim.x, L = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = L & 7;
+    const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    by = Lp / ar.nbx;
+    bx = Lp - by * ar.nbx;
+  }
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int wc = bx * W + w;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+  uint4 *s_b = reinterpret_cast<uint4 *>(smem_h);
+  float *s_gc = reinterpret_cast<float *>(smem_h + 2 * FTB * kTileU4 * 16) + w * (NT * 32);
+  for (int idx = lane; idx < NT * 32; idx += 64)
+    s_gc[idx] = pk.gcpack[(size_t)wc * (NT * 32) + idx];
+  const int colreg = lane < NT * 16 ? pk.segcol[(size_t)wc * (NT * 16) + lane] : kColDiscard;
+  uint32_t endm[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    endm[nt] = __builtin_amdgcn_readfirstlane(pk.endmask[wc * NT + nt]);
+
+  bf16x8 a[NT][KS][NP];  // raw 16-bit lanes; reinterpreted as fp16 when PREC = 1
+  {
+    const uint4 *ap = static_cast<const uint4 *>(pk.apack) + (size_t)wc * (NT * KS * NP * 64) + lane;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          a[nt][s][p] = __builtin_bit_cast(bf16x8, ap[((nt * KS + s) * NP + p) * 64]);
+  }
+
+  const int t_begin = by * ar.fpb;
+  const int t_end = min(ar.T, t_begin + ar.fpb);
+  const int ntile = t_begin < ar.T ? (t_end - t_begin + 31) >> 5 : 0;
+  const int ngroup = (ntile + FTB - 1) / FTB;
+  const uint4 *gtile = ar.bx + (size_t)(t_begin >> 5) * kTileU4;
+
+  auto stage = [&](int g) {
+    const int npiece = min(FTB, ntile - g * FTB) * (KS * NP);
+    for (int piece = w; piece < npiece; piece += W) {
+      const uint4 *src = gtile + (size_t)g * FTB * kTileU4 + piece * 64 + lane;
+      uint4 *dst = s_b + (g & 1) * FTB * kTileU4 + piece * 64;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+  };
+  if (ngroup > 0) stage(0);
+  if (ngroup > 1) stage(1);
+  __syncthreads();
+  if (ntile == 0) return;
+
+  constexpr int kMfma = KS * NPROD * NT;
+  constexpr int kSteps = NT * 16;
+  constexpr int kSkip = 2;
+  bf16x8 bf[2][NP];
+  auto load_b = [&](const uint4 *bt, int s) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) bf[s & 1][p] = __builtin_bit_cast(bf16x8, bt[(s * NP + p) * 64]);
+  };
+  auto mfma_n = [&](f32x16 (&acc)[NT], const uint4 *bt, int n) {
+    const int s = n / (NPROD * NT), r = n % (NPROD * NT), which = r / NT, nt = r % NT;
+    if (r == 0 && s + 1 < KS && !(ABL & 8)) load_b(bt, s + 1);
+    int pa, pb;  // (model part, feature part), small terms first
+    if (PREC) {
+      pa = which == 0 ? 1 : 0;
+      pb = which == 1 ? 1 : 0;
+    } else {
+      pa = which == 0 ? 2 : (which == 1 || which == 3) ? 1 : 0;
+      pb = (which == 0 || which == 3 || which == 5) ? 0 : (which == 1 || which == 4) ? 1 : 2;
+    }
+    if (PREC)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[nt][s][pa]),
+                                                       __builtin_bit_cast(f16x8, bf[s & 1][pb]),
+                                                       acc[nt], 0, 0, 0);
+    else
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][s][pa], bf[s & 1][pb], acc[nt], 0, 0, 0);
+  };
+  auto init_acc = [&](f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float4 *g4 = reinterpret_cast<const float4 *>(&s_gc[nt * 32 + h * 16]);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        float4 v = g4[q4];
+        acc[nt][4 * q4 + 0] = v.x;
+        acc[nt][4 * q4 + 1] = v.y;
+        acc[nt][4 * q4 + 2] = v.z;
+        acc[nt][4 * q4 + 3] = v.w;
+      }
+    }
+  };
+
+  f32x16 acc_cur[NT];
+  init_acc(acc_cur);
+  load_b(s_b + lane, 0);
+#pragma unroll
+  for (int n = 0; n < kMfma; ++n) mfma_n(acc_cur, s_b + lane, n);
+
+  for (int ft = 0; ft < ntile; ++ft) {
+    const int t0 = t_begin + (ft << 5);
+    const int row = t0 + j;
+    const bool row_ok = (row < t_end) && (h == 0);
+    float *orow = ar.out + (size_t)row * ar.ldo;
+    int seg = 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+s"(endm[nt]));
+
+    const int fn = ft + 1;
+    if (fn % FTB == 0 && !(ABL & 16)) {
+      __syncthreads();
+      const int g = fn / FTB;
+      if (g + 1 < ngroup) stage(g + 1);
+    }
+    const uint4 *bt = s_b + (((fn / FTB) & 1) * FTB + fn % FTB) * kTileU4 + lane;
+    f32x16 acc_next[NT];
+    init_acc(acc_next);
+    if (!(ABL & 8)) load_b(bt, 0);
+
+    // Reference of the segment that starts at register 0 of this frame tile.
+    float R, s_ = 0.0f;
+    {
+      float lo, hi;
+      both_halves(acc_cur[0][0], lo, hi);
+      R = fmaxf(lo, hi) + kRefShift;
+    }
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) {
+      const int nt = st >> 4, i = st & 15;
+#pragma unroll
+      for (int n = (max(st - kSkip, 0) * kMfma) / (kSteps - kSkip);
+           n < (max(st + 1 - kSkip, 0) * kMfma) / (kSteps - kSkip); ++n)
+        mfma_n(acc_next, bt, n);
+      if (ABL & 2) asm volatile("" ::"v"(acc_cur[nt][i]));  // keep the chain alive when timing
+      else s_ += fast_exp2(acc_cur[nt][i] - R);
+      if (((endm[nt] >> i) & 1u) && !(ABL & 4)) {  // wave-uniform: register i closes a pdf segment
+        const int col = __builtin_amdgcn_readlane(colreg, seg);
+        ++seg;
+        float s_lo, s_hi;
+        both_halves(s_, s_lo, s_hi);
+        const float S = s_lo + s_hi;
+        if (col >= 0) {
+          const float v = (R + fast_log2(S)) * kLn2;
+          if (row_ok && !(ABL & 1)) orow[col] = v;
+          if (row_ok && !ABL) {
+            if (!(fabsf(v) <= kMaxAbsLogLike)) {
+              const int k = atomicAdd(ar.ctl, 1);
+              if (k < ar.fix_cap) ar.fix_list[k] = make_int2(row, col);
+            }
+          }
+        } else if (col != kColDiscard) {
+          if (row_ok && !(ABL & 1)) {  // parts are merged in natural-log units
+            const size_t o = (size_t)(-col - 2) * ar.part_ld + row;
+            ar.part_m[o] = R * kLn2;
+            ar.part_s[o] = S;
+          }
+        }
+        if (st + 1 < kSteps) {
+          float lo, hi;
+          both_halves(acc_cur[(st + 1) >> 4][(st + 1) & 15], lo, hi);
+          R = fmaxf(lo, hi) + kRefShift;
+          s_ = 0.0f;
+        }
+      }
+    }
+    if (ABL & 4) asm volatile("" ::"v"(R), "v"(s_));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc_cur[nt] = acc_next[nt];
+  }
+}
+
+// Recomputes the listed (frame, pdf) pairs in plain fp32 with the reference's own
+// log-sum-exp (maximum first, then the sum); one wave per pair.
+__global__ void __launch_bounds__(256)
+    gmm_fix_kernel(const int *ctl, const int2 *fix_list, int fix_cap,
+                   const float *__restrict__ gconsts, const float *__restrict__ miv,
+                   const float *__restrict__ iv, const int32_t *__restrict__ offsets, int dim,
+                   const float *__restrict__ feats, int ld, float *out, int ldo, int *flag) {
+  if (ctl[1] != 0) return;
+  const int n = ctl[0];
+  if (n > fix_cap) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  for (int e = wave; e < n; e += nwaves) {
+    const int2 tp = fix_list[e];
+    const float *x = feats + (size_t)tp.x * ld;
+    const int g0 = offsets[tp.y], g1 = offsets[tp.y + 1];
+    float m = -INFINITY;
+    for (int g = g0 + lane; g < g1; g += 64) {
+      float a1 = 0.0f, a2 = 0.0f;
+      for (int d = 0; d < dim; ++d) {
+        const float xd = x[d];
+        a1 = fmaf(miv[(size_t)g * dim + d], xd, a1);
+        a2 = fmaf(iv[(size_t)g * dim + d], xd * xd, a2);
+      }
+      m = fmaxf(m, gconsts[g] + a1 - 0.5f * a2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.0f;
+    for (int g = g0 + lane; g < g1; g += 64) {
+      float a1 = 0.0f, a2 = 0.0f;
+      for (int d = 0; d < dim; ++d) {
+        const float xd = x[d];
+        a1 = fmaf(miv[(size_t)g * dim + d], xd, a1);
+        a2 = fmaf(iv[(size_t)g * dim + d], xd * xd, a2);
+      }
+      const float f = gconsts[g] + a1 - 0.5f * a2;
+      if (f - m >= -15.9423847198486328125f) sum += __expf(f - m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) {
+      const float v = m + __logf(sum);
+      out[(size_t)tp.x * ldo + tp.y] = v;
+      if (!(fabsf(v) <= kMaxAbsLogLike)) atomicOr(flag, 1);
+    }
+  }
+}
+
 // Merges the parts of pdfs that were split over several waves:
 // out[t][col] = log sum_parts s_p exp(m_p).   One thread per (split pdf, frame).
 struct SplitPdf {
@@ -541,7 +863,9 @@ struct SplitPdf {
 
 __global__ void gmm_merge_parts_kernel(const SplitPdf *splits, int num_splits,
                                        const float *part_m, const float *part_s, int part_ld,
-                                       int T, float *out, int ldo, int *flag) {
+                                       int T, float *out, int ldo, int *flag, int *ctl,
+                                       int2 *fix_list, int fix_cap, int guard) {
+  if (guard_skips(ctl, fix_cap, guard)) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int sp = blockIdx.y;
   if (t >= T || sp >= num_splits) return;
@@ -556,7 +880,14 @@ __global__ void gmm_merge_parts_kernel(const SplitPdf *splits, int num_splits,
   }
   const float v = M + kLn2 * fast_log2(S);
   out[(size_t)t * ldo + d.col] = v;
-  if (!(fabsf(v) <= kMaxAbsLogLike)) atomicOr(flag, 1);
+  if (!(fabsf(v) <= kMaxAbsLogLike)) {
+    if (guard == 1) {  // fast path: recompute this pair exactly
+      const int k = atomicAdd(ctl, 1);
+      if (k < fix_cap) fix_list[k] = make_int2(t, d.col);
+    } else {
+      atomicOr(flag, 1);
+    }
+  }
 }
 
 // Copies [T x dim] features with an arbitrary row stride into a 16-byte aligned
@@ -665,13 +996,17 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------
 // Host side: the packed model.
 
+typedef void (*ExpandFn)(const float *, int, int, int, uint4 *, int, const float *, int *, int, int);
 struct Variant {
-  int mode;  // 0: exact-fp32 MFMA kernel, 1: bf16x3 kernel
-  int D;     // mode 0: feature dimension; mode 1: KS = ceil(dim / 8) MFMA k-steps
+  int mode;  // 0: exact-fp32 MFMA kernel, 1: bf16x3 kernel, 2: fast kernel (+ bf16x3 fallback)
+  int D;     // mode 0: feature dimension; mode >= 1: KS = ceil(dim / 8) MFMA k-steps
   int NT, W;
   void (*kernel)(GmmPackView, ScoreArgs);
-  void (*expand)(const float *, int, int, int, uint4 *, int);  // bf16x3 feature prepass
+  ExpandFn expand;  // feature prepass of `kernel`
   const char *name;
+  int prec = 0;  // mode 2: 1 = fp16x2 operands, 0 = bf16x3 operands
+  void (*safe_kernel)(GmmPackView, ScoreArgs) = nullptr;  // mode 2: wide-range / exact fallback
+  ExpandFn safe_expand = nullptr;
 };
 
 #define AMLIKE_VARIANT(D, NT, W) \
@@ -679,6 +1014,17 @@ struct Variant {
 #define AMLIKE_VARIANT_H(KS, NT, W, OCC)                                                  \
   { 1, KS, NT, W, gmm_score_bf16x3_kernel<KS, NT, W, OCC>, gmm_expand_feats_kernel<KS>,   \
     "gmm_score_bf16x3_kernel<" #KS "," #NT "," #W "," #OCC ">" }
+#define AMLIKE_VARIANT_F(KS, NT, W, OCC, PREC)                                               \
+  { 2, KS, NT, W, gmm_score_fast_kernel<KS, NT, W, OCC, PREC>,                                \
+    PREC ? gmm_expand_feats_f16_kernel<KS> : gmm_expand_feats_kernel<KS>,                     \
+    PREC ? "gmm_score_fast_kernel<" #KS "," #NT "," #W "," #OCC ",f16x2>"                     \
+         : "gmm_score_fast_kernel<" #KS "," #NT "," #W "," #OCC ",bf16x3>",                   \
+    PREC, gmm_score_bf16x3_kernel<KS, NT, W, OCC>, gmm_expand_feats_kernel<KS> }
+#define AMLIKE_VARIANT_FABL(KS, NT, W, OCC, PREC, ABL)                                       \
+  { 200 + ABL, KS, NT, W, gmm_score_fast_kernel<KS, NT, W, OCC, PREC, ABL>,                   \
+    PREC ? gmm_expand_feats_f16_kernel<KS> : gmm_expand_feats_kernel<KS>,                     \
+    "gmm_score_fast_kernel<" #KS "," #NT "," #W "," #OCC "," #PREC ",ABL=" #ABL ">",          \
+    PREC, gmm_score_bf16x3_kernel<KS, NT, W, OCC>, gmm_expand_feats_kernel<KS> }
 #define AMLIKE_VARIANT_ABL(KS, NT, W, OCC, ABL)                                           \
   { 100 + ABL, KS, NT, W, gmm_score_bf16x3_kernel<KS, NT, W, OCC, ABL>,                   \
     gmm_expand_feats_kernel<KS>, "gmm_score_bf16x3_kernel<" #KS "," #NT "," #W "," #OCC ",ABL=" #ABL ">" }
@@ -688,6 +1034,14 @@ struct Variant {
 //         covers every feature dimension up to 64.
 // f32:    exact-fp32 MFMA, NT*D model registers per lane (AMLIKE_GMM_MODE=f32), D = 39 / 40.
 static const Variant kVariants[] = {
+    AMLIKE_VARIANT_F(5, 2, 8, 2, 1), AMLIKE_VARIANT_F(5, 2, 8, 2, 0),
+    AMLIKE_VARIANT_F(1, 2, 8, 2, 1), AMLIKE_VARIANT_F(1, 2, 8, 2, 0),
+    AMLIKE_VARIANT_F(2, 2, 8, 2, 1), AMLIKE_VARIANT_F(2, 2, 8, 2, 0),
+    AMLIKE_VARIANT_F(3, 2, 8, 2, 1), AMLIKE_VARIANT_F(3, 2, 8, 2, 0),
+    AMLIKE_VARIANT_F(4, 2, 8, 2, 1), AMLIKE_VARIANT_F(4, 2, 8, 2, 0),
+    AMLIKE_VARIANT_F(6, 1, 8, 2, 1), AMLIKE_VARIANT_F(6, 1, 8, 2, 0),
+    AMLIKE_VARIANT_F(7, 1, 8, 2, 1), AMLIKE_VARIANT_F(7, 1, 8, 2, 0),
+    AMLIKE_VARIANT_F(8, 1, 8, 2, 1), AMLIKE_VARIANT_F(8, 1, 8, 2, 0),
     AMLIKE_VARIANT_H(5, 2, 8, 2), AMLIKE_VARIANT_H(5, 2, 4, 2),
     AMLIKE_VARIANT_H(1, 2, 8, 2), AMLIKE_VARIANT_H(2, 2, 8, 2), AMLIKE_VARIANT_H(3, 2, 8, 2),
     AMLIKE_VARIANT_H(4, 2, 8, 2), AMLIKE_VARIANT_H(6, 1, 8, 2), AMLIKE_VARIANT_H(7, 1, 8, 2),
@@ -695,6 +1049,10 @@ static const Variant kVariants[] = {
 #ifdef AMLIKE_ABLATION_BUILD
     AMLIKE_VARIANT_ABL(5, 2, 8, 2, 1), AMLIKE_VARIANT_ABL(5, 2, 8, 2, 6), AMLIKE_VARIANT_ABL(5, 2, 8, 2, 14),
     AMLIKE_VARIANT_ABL(5, 2, 8, 2, 30), AMLIKE_VARIANT_ABL(5, 2, 8, 2, 4),
+    AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 1), AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 2),
+    AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 4), AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 6),
+    AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 14), AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 30),
+    AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 8),
 #endif
     AMLIKE_VARIANT(40, 3, 8), AMLIKE_VARIANT(39, 3, 8),
     AMLIKE_VARIANT(40, 6, 4), AMLIKE_VARIANT(39, 6, 4),
@@ -718,6 +1076,9 @@ struct amlike_gmm {
   double fill = 0.0;  // used slots / allocated slots
   // device arrays
   void *d_apack = nullptr;
+  void *d_apack_safe = nullptr;  // mode 2 with fp16x2 operands: the bf16x3 image for the fallback
+  float *d_bscale = nullptr;     // mode 2: per k-row feature scale [2][KS * 8]
+  int *d_ctl = nullptr;          // mode 2: {overflow count, range flag}
   float *d_gcpack = nullptr;
   uint32_t *d_endmask = nullptr;
   int32_t *d_segcol = nullptr;
@@ -727,26 +1088,30 @@ struct amlike_gmm {
   int32_t *d_offsets = nullptr;  // [num_pdfs + 1]
   std::vector<int32_t> pdf_offsets;
   hipStream_t stream = nullptr;  // used by the host-pointer entry points
-  DeviceBuffer ws_feats, ws_out, ws_part, ws_pad, ws_expand, ws_gauss;
+  DeviceBuffer ws_feats, ws_out, ws_part, ws_pad, ws_expand, ws_expand_safe, ws_fix, ws_gauss;
   std::mutex mu;
   std::string info;
 };
 
 namespace amlike {
 
-// AMLIKE_GMM_MODE = "f32" | "bf16x3" and AMLIKE_GMM_VARIANT = "<NT>x<W>" narrow the choice
-// (tuning / A-B aids); by default the first matching entry of kVariants is taken.
-static const Variant *ChooseVariant(int dim) {
+// AMLIKE_GMM_MODE = "fast-f16x2" | "fast-bf16x3" | "bf16x3" | "f32" and
+// AMLIKE_GMM_VARIANT = "<NT>x<W>" narrow the choice (tuning / A-B aids); by default the
+// first matching entry of kVariants is taken.  f16_ok: the model fits the fp16x2 operands.
+static const Variant *ChooseVariant(int dim, bool f16_ok) {
   const char *force = getenv("AMLIKE_GMM_VARIANT");
   const char *mode = getenv("AMLIKE_GMM_MODE");
   for (const Variant &v : kVariants) {
     if (v.mode == 0 && v.D != dim) continue;
     if (v.mode >= 1 && v.D != (dim + 7) / 8) continue;
-    if (v.mode >= 100) {  // ablation instantiations: only by explicit request "abl<N>"
+    if ((v.mode == 2 || v.mode >= 200) && v.prec == 1 && !f16_ok) continue;
+    const char *vname = v.mode == 0 ? "f32" : v.mode == 1 ? "bf16x3" : v.prec ? "fast-f16x2" : "fast-bf16x3";
+    if (v.mode >= 100) {  // ablation instantiations: only by explicit request "abl<N>" / "fabl<N>"
       char want[32];
-      snprintf(want, sizeof(want), "abl%d", v.mode - 100);
+      if (v.mode >= 200) snprintf(want, sizeof(want), "fabl%d", v.mode - 200);
+      else snprintf(want, sizeof(want), "abl%d", v.mode - 100);
       if (!mode || strcmp(mode, want) != 0) continue;
-    } else if (mode && strcmp(mode, v.mode == 0 ? "f32" : "bf16x3") != 0) {
+    } else if (mode && strcmp(mode, vname) != 0) {
       continue;
     }
     if (force) {
@@ -782,6 +1147,47 @@ static inline void SplitBf16x3(float x, uint16_t p[3]) {
   p[2] = Bf16Rne(r);
 }
 
+// x ~= p[0] + p[1] to 22 bits (two fp16); exact powers of two scale it beforehand.
+static inline void SplitF16x2(float x, uint16_t p[2]) {
+  const _Float16 h1 = static_cast<_Float16>(x);
+  const _Float16 h2 = static_cast<_Float16>(x - static_cast<float>(h1));
+  memcpy(&p[0], &h1, 2);
+  memcpy(&p[1], &h2, 2);
+}
+
+// Chooses, for every k-row of the contraction (kind 0: miv_d * x_d, kind 1: -0.5 iv_d * x_d^2),
+// a power-of-two scale that balances the largest model value against the largest feature value
+// the model itself makes plausible (|mean| + 8 sigma over all Gaussians), so that both operands
+// of the fp16x2 kernel stay far from the ends of the fp16 range.  Returns false when some row
+// cannot be balanced into [0, 16384]: the model then runs on the bf16x3 operands.
+static bool ComputeF16Scales(const float *gconsts, const float *miv, const float *iv, int G, int D,
+                             int KS, std::vector<float> *ascale, std::vector<float> *bscale) {
+  ascale->assign((size_t)2 * KS * 8, 1.0f);
+  bscale->assign((size_t)2 * KS * 8, 1.0f);
+  for (int d = 0; d < D; ++d) {
+    double amax[2] = {0.0, 0.0}, xr = 0.0;
+    for (int g = 0; g < G; ++g) {
+      if (!std::isfinite(gconsts[g])) continue;
+      const double v = iv[(size_t)g * D + d], m = miv[(size_t)g * D + d];
+      if (!(v > 0.0) || !std::isfinite(v) || !std::isfinite(m)) return false;
+      amax[0] = std::max(amax[0], std::fabs(m) * kLog2e);
+      amax[1] = std::max(amax[1], 0.5 * v * kLog2e);
+      xr = std::max(xr, std::fabs(m / v) + 8.0 / std::sqrt(v));
+    }
+    for (int kind = 0; kind < 2; ++kind) {
+      const double bmax = kind ? xr * xr : xr;
+      int e = 0;
+      if (amax[kind] > 0.0 && bmax > 0.0)
+        e = (int)std::lround(0.5 * (std::log2(bmax) - std::log2(amax[kind])));
+      e = std::max(-60, std::min(60, e));
+      if (std::ldexp(amax[kind], e) > 16384.0 || std::ldexp(bmax, -e) > 16384.0) return false;
+      (*ascale)[(size_t)kind * KS * 8 + d] = std::ldexp(1.0f, e);
+      (*bscale)[(size_t)kind * KS * 8 + d] = std::ldexp(1.0f, -e);
+    }
+  }
+  return true;
+}
+
 // Packs the model for `v`.
 //
 // A wave-chunk is NT tiles x 32 slots.  Every pdf takes an even number of
@@ -793,8 +1199,11 @@ static inline void SplitBf16x3(float x, uint16_t p[3]) {
 // of a chunk, a short look-ahead picks a later one that does.  A pdf larger
 // than a whole chunk is cut into parts whose (max,sum) are merged afterwards.
 static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, const float *iv,
-                     const int32_t *offs) {
+                     const int32_t *offs, const std::vector<float> &ascale,
+                     const std::vector<float> &bscale) {
   const Variant &v = *g->variant;
+  const bool fast = v.mode == 2 || v.mode >= 200;
+  const bool f16 = fast && v.prec == 1;
   const int D = g->dim, NT = v.NT, W = v.W, DQ = (D + 3) / 4, KS = (D + 7) / 8;
   const int cap = NT * 32;
   std::vector<Piece> pieces;
@@ -866,9 +1275,17 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
   // Operand image.  mode 0: fp32 [wc][nt][dq][lane][4]; mode 1: bf16 [wc][nt][s][part][lane][8],
   // values pre-multiplied by log2(e), lane (r, h): h=0 -> miv, h=1 -> -0.5 iv, d = 8s + jj.
   std::vector<float> apack;
-  std::vector<uint16_t> apack_h;
+  std::vector<uint16_t> apack_h, apack_f;  // bf16x3 image; fp16x2 image
   if (v.mode == 0) apack.assign((size_t)num_wc * NT * DQ * 64 * 4, 0.0f);
   else apack_h.assign((size_t)num_wc * NT * KS * 3 * 64 * 8, 0);
+  if (f16) apack_f.assign((size_t)num_wc * NT * KS * 2 * 64 * 8, 0);
+  // Broadness of a Gaussian: sum_d log(inv var), smaller = broader.
+  std::vector<float> logdet(g->num_gauss);
+  for (int gi = 0; gi < g->num_gauss; ++gi) {
+    double acc = 0.0;
+    for (int d = 0; d < D; ++d) acc += std::log(std::max(iv[(size_t)gi * D + d], 1e-30f));
+    logdet[gi] = (float)acc;
+  }
   std::vector<float> gcpack((size_t)num_wc * NT * 32,
                             v.mode == 0 ? -std::numeric_limits<float>::infinity() : kPadGconst);
   std::vector<uint32_t> endmask((size_t)num_wc * NT, 0u);
@@ -877,8 +1294,9 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
   for (int wc = 0; wc < num_wc; ++wc) {
     int slot = 0, seg = 0;
     for (const Piece &p : chunks[wc]) {
-      // Gaussians with gconst = -inf (zero weight) go last within their pdf, so that
-      // the first element each half-wave sees of a segment is a live one.
+      // Gaussians with gconst = -inf (zero weight) go last within their pdf, the live ones
+      // broadest first: the first element each half-wave sees of a segment is then a live
+      // one, and the one least likely to be far below the segment's maximum.
       order.resize(p.count);
       {
         int lo = 0, hi = p.count;
@@ -886,6 +1304,8 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
           if (std::isfinite(gconsts[p.g_begin + q])) order[lo++] = p.g_begin + q;
         for (int q = p.count - 1; q >= 0; --q)
           if (!std::isfinite(gconsts[p.g_begin + q])) order[--hi] = p.g_begin + q;
+        std::stable_sort(order.begin(), order.begin() + lo,
+                         [&](int x, int y) { return logdet[x] < logdet[y]; });
       }
       for (int q = 0; q < p.count; ++q) {
         const int n = slot + q, nt = n >> 5, nn = n & 31, i = nn >> 1, hh = nn & 1;
@@ -900,6 +1320,7 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
           }
         } else {
           gcpack[((size_t)wc * NT + nt) * 32 + hh * 16 + i] = std::max(gconsts[gi] * kLog2e, kPadGconst);
+          const bool live = std::isfinite(gconsts[gi]);
           for (int d = 0; d < D; ++d) {
             const int s = d >> 3, jj = d & 7;
             uint16_t pm[3], pv[3];
@@ -909,6 +1330,16 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
               const size_t base = (((((size_t)wc * NT + nt) * KS + s) * 3 + part) * 64) * 8 + jj;
               apack_h[base + (size_t)r * 8] = pm[part];
               apack_h[base + (size_t)(r + 32) * 8] = pv[part];
+            }
+            if (f16 && live) {  // a disabled Gaussian keeps zero operands: its score is the pad gconst
+              uint16_t qm[2], qv[2];
+              SplitF16x2(miv[gi * D + d] * kLog2e * ascale[d], qm);
+              SplitF16x2(-0.5f * iv[gi * D + d] * kLog2e * ascale[(size_t)KS * 8 + d], qv);
+              for (int part = 0; part < 2; ++part) {
+                const size_t base = (((((size_t)wc * NT + nt) * KS + s) * 2 + part) * 64) * 8 + jj;
+                apack_f[base + (size_t)r * 8] = qm[part];
+                apack_f[base + (size_t)(r + 32) * 8] = qv[part];
+              }
             }
           }
         }
@@ -930,7 +1361,14 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
     }
   }
 
-  if (v.mode >= 1) {
+  if (f16) {
+    AMLIKE_HIP(hipMalloc(&g->d_apack, apack_f.size() * sizeof(uint16_t)));
+    AMLIKE_HIP(hipMemcpy(g->d_apack, apack_f.data(), apack_f.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    AMLIKE_HIP(hipMalloc(&g->d_apack_safe, apack_h.size() * sizeof(uint16_t)));
+    AMLIKE_HIP(hipMemcpy(g->d_apack_safe, apack_h.data(), apack_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    AMLIKE_HIP(hipMalloc(&g->d_bscale, bscale.size() * sizeof(float)));
+    AMLIKE_HIP(hipMemcpy(g->d_bscale, bscale.data(), bscale.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else if (v.mode >= 1) {
     AMLIKE_HIP(hipMalloc(&g->d_apack, apack_h.size() * sizeof(uint16_t)));
     AMLIKE_HIP(hipMemcpy(g->d_apack, apack_h.data(), apack_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   } else {
@@ -943,6 +1381,10 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
   AMLIKE_HIP(hipMemcpy(g->d_gcpack, gcpack.data(), gcpack.size() * sizeof(float), hipMemcpyHostToDevice));
   AMLIKE_HIP(hipMemcpy(g->d_endmask, endmask.data(), endmask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   AMLIKE_HIP(hipMemcpy(g->d_segcol, segcol.data(), segcol.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (fast) {
+    AMLIKE_HIP(hipMalloc(&g->d_ctl, 2 * sizeof(int)));
+    AMLIKE_HIP(hipMemset(g->d_ctl, 0, 2 * sizeof(int)));
+  }
   if (!splits.empty()) {
     AMLIKE_HIP(hipMalloc(&g->d_splits, splits.size() * sizeof(SplitPdf)));
     AMLIKE_HIP(hipMemcpy(g->d_splits, splits.data(), splits.size() * sizeof(SplitPdf), hipMemcpyHostToDevice));
@@ -969,23 +1411,6 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
   ScoreArgs ar;
   ar.feats = d_feats;
   ar.bx = nullptr;
-  size_t smem = 0;
-  if (v.mode >= 1) {
-    // Feature prepass: fp32 [T x dim] -> bf16x3 operand tiles (480 B per frame at D=40).
-    const int KS = v.D, num_ftiles = (T + 31) / 32;
-    const size_t tile_bytes = (size_t)KS * 3 * 64 * 16;
-    int rc = g->ws_expand.Reserve((size_t)num_ftiles * tile_bytes);
-    if (rc != AMLIKE_OK) return rc;
-    ar.bx = static_cast<const uint4 *>(g->ws_expand.ptr);
-    const int threads = num_ftiles * KS * 64;
-    hipLaunchKernelGGL(v.expand, dim3((threads + 255) / 256), dim3(256), 0, stream, d_feats, T, ld,
-                       g->dim, static_cast<uint4 *>(g->ws_expand.ptr), num_ftiles);
-    AMLIKE_HIP(hipGetLastError());
-    smem = 2 * FramesTilesPerBarrier(v.W, KS) * tile_bytes + (size_t)v.W * v.NT * 32 * 4;
-    if (smem > 64 * 1024)
-      AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(v.kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  }
   ar.T = T;
   ar.ld = ld;
   ar.out = d_out;
@@ -995,6 +1420,10 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
   ar.part_m = ar.part_s = nullptr;
   ar.part_ld = 0;
   ar.flag = g->d_flag;
+  ar.ctl = g->d_ctl;
+  ar.fix_list = nullptr;
+  ar.fix_cap = 0;
+  ar.guard = 0;
   if (g->num_partials > 0) {
     const int part_ld = (T + 31) & ~31;
     int rc = g->ws_part.Reserve((size_t)2 * g->num_partials * part_ld * sizeof(float));
@@ -1003,14 +1432,63 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
     ar.part_s = ar.part_m + (size_t)g->num_partials * part_ld;
     ar.part_ld = part_ld;
   }
-  GmmPackView pk{g->d_apack, g->d_gcpack, g->d_endmask, g->d_segcol, g->num_wc};
-  hipLaunchKernelGGL(v.kernel, dim3(nbx * nby), dim3(64 * v.W), smem, stream, pk, ar);
-  AMLIKE_HIP(hipGetLastError());
-  if (g->num_splits > 0) {
-    hipLaunchKernelGGL(gmm_merge_parts_kernel, dim3((T + 255) / 256, g->num_splits), dim3(256), 0,
-                       stream, g->d_splits, g->num_splits, ar.part_m, ar.part_s, ar.part_ld, T,
-                       d_out, ldo, g->d_flag);
+  const int KS = v.D, num_ftiles = (T + 31) / 32;
+  // One scoring pass: feature prepass (mode >= 1), the kernel, the merge of split pdfs.
+  auto pass = [&](void (*kernel)(GmmPackView, ScoreArgs), ExpandFn expand, int parts,
+                  const void *apack, DeviceBuffer *ws, int guard) -> int {
+    size_t smem = 0;
+    ScoreArgs a = ar;
+    a.guard = guard;
+    if (expand) {
+      // fp32 [T x dim] -> operand tiles (160 B per frame, part and k-step).
+      const size_t tile_bytes = (size_t)KS * parts * 64 * 16;
+      int rc = ws->Reserve((size_t)num_ftiles * tile_bytes);
+      if (rc != AMLIKE_OK) return rc;
+      a.bx = static_cast<const uint4 *>(ws->ptr);
+      const int threads = num_ftiles * KS * 64;
+      hipLaunchKernelGGL(expand, dim3((threads + 255) / 256), dim3(256), 0, stream, d_feats, T, ld,
+                         g->dim, static_cast<uint4 *>(ws->ptr), num_ftiles, g->d_bscale, g->d_ctl,
+                         a.fix_cap, guard == 2 ? 2 : 0);
+      AMLIKE_HIP(hipGetLastError());
+      smem = 2 * FramesTilesPerBarrier(v.W, KS, parts) * tile_bytes + (size_t)v.W * v.NT * 32 * 4;
+      if (smem > 64 * 1024)
+        AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
+    GmmPackView pk{apack, g->d_gcpack, g->d_endmask, g->d_segcol, g->num_wc};
+    hipLaunchKernelGGL(kernel, dim3(nbx * nby), dim3(64 * v.W), smem, stream, pk, a);
     AMLIKE_HIP(hipGetLastError());
+    if (g->num_splits > 0 && v.mode < 100) {
+      hipLaunchKernelGGL(gmm_merge_parts_kernel, dim3((T + 255) / 256, g->num_splits), dim3(256), 0,
+                         stream, g->d_splits, g->num_splits, a.part_m, a.part_s, a.part_ld, T, d_out,
+                         ldo, g->d_flag, g->d_ctl, a.fix_list, a.fix_cap, guard);
+      AMLIKE_HIP(hipGetLastError());
+    }
+    return AMLIKE_OK;
+  };
+  if (v.mode == 2 || v.mode >= 200) {
+    // Fast pass, exact repair of the few pairs whose sum overflowed, and a full pass of the
+    // wide-range kernel that runs only when the fast pass could not be used (decided on
+    // the device: features outside the fp16 range, or more overflows than the list holds).
+    const size_t cap = std::max<size_t>(4096, std::min<size_t>((size_t)1 << 21, (size_t)T * g->num_pdfs / 256));
+    int rc = g->ws_fix.Reserve(cap * sizeof(int2));
+    if (rc != AMLIKE_OK) return rc;
+    ar.fix_list = static_cast<int2 *>(g->ws_fix.ptr);
+    ar.fix_cap = (int)cap;
+    AMLIKE_HIP(hipMemsetAsync(g->d_ctl, 0, 2 * sizeof(int), stream));
+    rc = pass(v.kernel, v.expand, v.prec ? 2 : 3, g->d_apack, &g->ws_expand, 1);
+    if (rc != AMLIKE_OK) return rc;
+    if (v.mode >= 200) return AMLIKE_OK;  // timing experiments: the main kernel alone
+    hipLaunchKernelGGL(gmm_fix_kernel, dim3(64), dim3(256), 0, stream, g->d_ctl, ar.fix_list, ar.fix_cap,
+                       g->d_gconsts, g->d_miv, g->d_iv, g->d_offsets, g->dim, d_feats, ld, d_out, ldo,
+                       g->d_flag);
+    AMLIKE_HIP(hipGetLastError());
+    rc = pass(v.safe_kernel, v.safe_expand, 3, v.prec ? g->d_apack_safe : g->d_apack,
+              v.prec ? &g->ws_expand_safe : &g->ws_expand, 2);
+    if (rc != AMLIKE_OK) return rc;
+  } else {
+    int rc = pass(v.kernel, v.mode >= 1 ? v.expand : nullptr, 3, g->d_apack, &g->ws_expand, 0);
+    if (rc != AMLIKE_OK) return rc;
   }
   char buf[256];
   snprintf(buf, sizeof(buf), "%s grid=%d block=%d frames_per_block=%d wave_chunks=%d fill=%.4f splits=%d",
@@ -1075,7 +1553,10 @@ int amlike_gmm_create(const float *gconsts, const float *means_invvars, const fl
     int rc = amlike_init(0);
     if (rc != AMLIKE_OK) return rc;
   }
-  const Variant *v = ChooseVariant(dim);
+  std::vector<float> ascale, bscale;
+  const bool f16_ok = ComputeF16Scales(gconsts, means_invvars, inv_vars, num_gauss, dim,
+                                       (dim + 7) / 8, &ascale, &bscale);
+  const Variant *v = ChooseVariant(dim, f16_ok);
   if (!v) {
     SetError("amlike_gmm_create: no kernel for feature dimension %d", dim);
     return AMLIKE_EDIM;
@@ -1087,7 +1568,7 @@ int amlike_gmm_create(const float *gconsts, const float *means_invvars, const fl
   g->device = CurrentDevice();
   g->variant = v;
   g->pdf_offsets.assign(pdf_offsets, pdf_offsets + num_pdfs + 1);
-  int rc = PackModel(g, gconsts, means_invvars, inv_vars, pdf_offsets);
+  int rc = PackModel(g, gconsts, means_invvars, inv_vars, pdf_offsets, ascale, bscale);
   if (rc == AMLIKE_OK) {
     auto up = [&](float **dst, const float *src, size_t n) -> int {
       AMLIKE_HIP(hipMalloc(dst, n * sizeof(float)));
@@ -1128,6 +1609,11 @@ int amlike_gmm_create(const float *gconsts, const float *means_invvars, const fl
 int amlike_gmm_destroy(amlike_gmm_t *g) {
   if (!g) return AMLIKE_OK;
   (void)hipFree(g->d_apack);
+  (void)hipFree(g->d_apack_safe);
+  (void)hipFree(g->d_bscale);
+  (void)hipFree(g->d_ctl);
+  g->ws_expand_safe.Free();
+  g->ws_fix.Free();
   (void)hipFree(g->d_gcpack);
   (void)hipFree(g->d_endmask);
   (void)hipFree(g->d_segcol);
