@@ -59,14 +59,9 @@ constexpr float kLn2 = 0.69314718055994530942f;
 // bf16x3 kernel: feature tiles staged per block barrier (LDS: 2 groups x this x 15 KiB at D=40;
 // 8-wave blocks own a CU's LDS alone, 4-wave blocks share it two per CU).
 constexpr int FramesTilesPerBarrier(int waves, int ks, int parts = 3) {
-  const int budget = waves == 8 ? 120 * 1024 : 60 * 1024, pair = 2 * ks * parts * 64 * 16;
+  const int budget = waves >= 8 ? 120 * 1024 : 60 * 1024, pair = 2 * ks * parts * 64 * 16;
   return budget / pair >= 4 ? 4 : budget / pair >= 2 ? 2 : 1;
 }
-// Reference-based log-sum-exp of the fast kernel: a segment's running sum is kept relative
-// to R = (score of its first Gaussian pair) + kRefShift in log2 units, so the first term
-// is 2^-kRefShift (a normal float) and later terms may exceed it by up to 2^227 before
-// the sum overflows; overflowed (frame, pdf) pairs are recomputed exactly afterwards.
-constexpr float kRefShift = 100.0f;
 // fp16x2 operands: scaled feature values beyond this magnitude send the launch to the
 // wide-range (bf16x3) kernel.
 constexpr float kF16Limit = 60000.0f;
@@ -95,12 +90,31 @@ struct ScoreArgs {
   // Fast-path bookkeeping.  ctl[0]: number of (frame, pdf) pairs whose sum overflowed
   // (listed in fix_list up to fix_cap); ctl[1]: nonzero when the features do not fit the
   // fp16 operand range.  guard 0: always run; 1: run unless ctl[1]; 2: run only when the
-  // fast path could not finish (ctl[1] set, or more overflows than fix_cap).
+  // differenced kernel could not finish (ctl[1] set, or more overflows than fix_cap).
   int *ctl;
   int2 *fix_list;
   int fix_cap;
   int guard;
 };
+
+// An empty volatile asm that takes and returns `x` in vector registers: instructions that
+// produce x stay before it and instructions that use x stay after it in program order.
+template <typename T>
+__device__ __forceinline__ void pin_order(T &x) {
+#if __HIP_DEVICE_COMPILE__  // the host pass cannot parse the vector-register constraints
+  asm volatile("" : "+v"(x));
+#endif
+}
+
+// 1.0f when bit `bit` of the wave-uniform `mask` is set, else 0.0f, computed on the scalar
+// unit (the compiler would otherwise turn it into a v_cndmask per use).
+__device__ __forceinline__ float scalar_bit_as_float(uint32_t mask, int bit) {
+  float r = 0.0f;
+#if __HIP_DEVICE_COMPILE__  // the host pass cannot parse the scalar-register constraints
+  asm volatile("s_bitcmp1_b32 %1, %2\n\ts_cselect_b32 %0, 1.0, 0" : "=s"(r) : "s"(mask), "s"(bit) : "scc");
+#endif
+  return r;
+}
 
 __device__ __forceinline__ bool guard_skips(const int *ctl, int fix_cap, int guard) {
   if (guard == 0) return false;
@@ -369,7 +383,7 @@ __global__ void __launch_bounds__(256)
   o[128] = pack(p3);
 }
 
-// fp16x2 operand image of the features for the fast kernel: [frame tile][KS][2 parts][64 lanes]
+// fp16x2 operand image of the features for the differenced kernel: [frame tile][KS][2 parts][64 lanes]
 // 8 x fp16.  Value k of a lane is x_d (h = 0) or x_d^2 (h = 1) times bscale[h][d], an exact
 // power of two chosen with the model (PackModel) so that both operands sit well inside the
 // fp16 range; x' = p1 + p2 to 22 bits.  A value outside the range sets ctl[1].
@@ -602,33 +616,40 @@ __global__ void __launch_bounds__(64 * W, OCC)
 
 
 // ---------------------------------------------------------------------------
-// The fast scoring kernel.  Same structure as gmm_score_bf16x3_kernel above (model
-// operands stationary in registers, expanded features staged through LDS, matrix
-// instructions of frame tile k+1 interleaved with the log-sum-exp of tile k), with
-// two changes that halve the work per (Gaussian, frame):
+// The default scoring kernel ("differenced").  Same skeleton as gmm_score_bf16x3_kernel
+// (model operands stationary in registers, expanded features staged through LDS, matrix
+// instructions of frame tile k+1 interleaved with the log-sum-exp of tile k), with two
+// changes that halve the matrix work and shrink the vector work per (Gaussian, frame):
 //
 //  PREC = 1: fp16x2 operands.  With 11 mantissa bits per fp16, value = p1 + p2 carries
-//    22 bits and the product needs three partial products (a2b1, a1b2, a1b1) instead
-//    of six; PackModel scales every k-row by a power of two so both operands stay in
-//    the fp16 range, and the feature prepass reports values that do not (the launch
-//    then falls back to the bf16x3 kernel, which has the fp32 exponent range).
-//    PREC = 0 keeps the bf16x3 operands.
+//    22 bits and a product needs three partial products (a2 b1, a1 b2, a1 b1) instead of the
+//    six of bf16x3.  PackModel scales every k-row by a power of two so that both operands
+//    stay inside the fp16 range, and the feature prepass reports values that do not (the
+//    launch then runs the bf16x3 kernel, which has the fp32 exponent range).  PREC = 0
+//    keeps bf16x3 operands (models that cannot be balanced into the fp16 range).
 //
-//  The log-sum-exp of a pdf segment is taken relative to a reference fixed at the
-//    segment's first register, R = max(f of its first Gaussian in either half-wave)
-//    + kRefShift: per element that is v_sub, v_exp, v_add (16 issue cycles) instead of
-//    the 7-instruction running-maximum update (32).  PackModel puts each pdf's broadest
-//    Gaussians first, which makes an overflow of the sum (some Gaussian more than
-//    2^227 above the reference) a rare event; such (frame, pdf) pairs are appended to
-//    fix_list and recomputed exactly by gmm_fix_kernel.
+//  The model is packed relative to a reference Gaussian per pdf segment (PackModel,
+//    "differenced" image): slot 0 of a segment holds the reference itself (its score
+//    f_ref), every other slot holds (Gaussian - reference), so the matrix instructions
+//    deliver d_i = f_i - f_ref directly and
+//        log sum_i exp f_i = f_ref + log(1 + sum_{i>0} exp d_i).
+//    The per-register work is v_exp_f32 + v_fma_f32 with a wave-uniform 0/1 factor that
+//    restarts the sum at segment boundaries; the pass over the 16*NT accumulator registers
+//    has no branch.  Every running sum is kept (sv), and a short loop over the wave's
+//    segments picks the sums at the segment ends by register index, joins the two
+//    half-waves and writes the results.  A sum that overflows (some Gaussian more than
+//    2^128 above the reference; PackModel makes the broadest Gaussian the reference, which
+//    keeps that rare) is listed in fix_list and recomputed exactly by gmm_fix_kernel.
 template <int KS, int NT, int W, int OCC, int PREC, int ABL = 0>
 __global__ void __launch_bounds__(64 * W, OCC)
-    gmm_score_fast_kernel(GmmPackView pk, ScoreArgs ar) {
-  constexpr int NP = PREC ? 2 : 3;    // parts per operand value
-  constexpr int NPROD = PREC ? 3 : 6; // partial products per k-step
+    gmm_score_diff_kernel(GmmPackView pk, ScoreArgs ar) {
+  constexpr int NP = PREC ? 2 : 3;
+  constexpr int NPROD = PREC ? 3 : 6;
   constexpr int kTileU4 = KS * NP * 64;
   constexpr int FTB = FramesTilesPerBarrier(W, KS, NP);
-  static_assert(NT * 16 <= 64, "segment columns are held one per lane");
+  constexpr int kSteps = NT * 16;
+  static_assert(NT == 1 || NT == 2, "segment masks are 32 bits");
+  typedef float svec __attribute__((ext_vector_type(kSteps)));
   if (guard_skips(ar.ctl, ar.fix_cap, ar.guard)) return;
   int bx, by;
   {
@@ -648,13 +669,27 @@ __global__ void __launch_bounds__(64 * W, OCC)
   float *s_gc = reinterpret_cast<float *>(smem_h + 2 * FTB * kTileU4 * 16) + w * (NT * 32);
   for (int idx = lane; idx < NT * 32; idx += 64)
     s_gc[idx] = pk.gcpack[(size_t)wc * (NT * 32) + idx];
-  const int colreg = lane < NT * 16 ? pk.segcol[(size_t)wc * (NT * 16) + lane] : kColDiscard;
-  uint32_t endm[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-    endm[nt] = __builtin_amdgcn_readfirstlane(pk.endmask[wc * NT + nt]);
+  const int colreg = lane < kSteps ? pk.segcol[(size_t)wc * kSteps + lane] : kColDiscard;
+  // Segment structure of this wave's chunk, all wave-uniform: bit r of `em` = register r
+  // closes a segment; keep bit r = the running sum continues into register r (it does not
+  // at a segment's first register, nor at the next one, which drops the reference's term).
+  uint32_t em = __builtin_amdgcn_readfirstlane(pk.endmask[wc * NT]);
+  if (NT == 2) em |= (uint32_t)__builtin_amdgcn_readfirstlane(pk.endmask[wc * NT + 1]) << 16;
+  const uint32_t startm = (em << 1) | 1u;
+  uint32_t keepm = ~(startm | (startm << 1));
+  const int nseg = __builtin_popcount(em);
+  const int npair = (nseg + 1) >> 1;
+  int endreg = kSteps - 1;  // lane k: last register of segment k
+  {
+    int seen = 0;
+    for (int r = 0; r < kSteps; ++r)
+      if ((em >> r) & 1u) {
+        if (seen == lane) endreg = r;
+        ++seen;
+      }
+  }
 
-  bf16x8 a[NT][KS][NP];  // raw 16-bit lanes; reinterpreted as fp16 when PREC = 1
+  bf16x8 a[NT][KS][NP];
   {
     const uint4 *ap = static_cast<const uint4 *>(pk.apack) + (size_t)wc * (NT * KS * NP * 64) + lane;
 #pragma unroll
@@ -687,16 +722,25 @@ __global__ void __launch_bounds__(64 * W, OCC)
   if (ntile == 0) return;
 
   constexpr int kMfma = KS * NPROD * NT;
-  constexpr int kSteps = NT * 16;
   constexpr int kSkip = 2;
-  bf16x8 bf[2][NP];
+#ifndef AMLIKE_DIFF_PRE
+#define AMLIKE_DIFF_PRE 2
+#endif
+  // Feature fragments are requested from LDS kPre k-steps before the matrix instructions
+  // that read them (a wave that waits on LDS issues nothing, its matrix work included).
+  constexpr int kPre = AMLIKE_DIFF_PRE < KS ? AMLIKE_DIFF_PRE : (KS > 1 ? KS - 1 : 1);
+  constexpr int NB = kPre + 1;
+  bf16x8 bf[NB][NP];
   auto load_b = [&](const uint4 *bt, int s) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) bf[s & 1][p] = __builtin_bit_cast(bf16x8, bt[(s * NP + p) * 64]);
+    for (int p = 0; p < NP; ++p) bf[s % NB][p] = __builtin_bit_cast(bf16x8, bt[(s * NP + p) * 64]);
   };
+  // The gconst image of this lane's accumulator registers, kept for the life of the wave:
+  // the first matrix instruction of every chain takes it as its C operand.
+  f32x16 gcv[NT];
   auto mfma_n = [&](f32x16 (&acc)[NT], const uint4 *bt, int n) {
     const int s = n / (NPROD * NT), r = n % (NPROD * NT), which = r / NT, nt = r % NT;
-    if (r == 0 && s + 1 < KS && !(ABL & 8)) load_b(bt, s + 1);
+    if (r == 0 && s + kPre < KS && !(ABL & 8)) load_b(bt, s + kPre);
     int pa, pb;  // (model part, feature part), small terms first
     if (PREC) {
       pa = which == 0 ? 1 : 0;
@@ -705,42 +749,40 @@ __global__ void __launch_bounds__(64 * W, OCC)
       pa = which == 0 ? 2 : (which == 1 || which == 3) ? 1 : 0;
       pb = (which == 0 || which == 3 || which == 5) ? 0 : (which == 1 || which == 4) ? 1 : 2;
     }
+    const f32x16 c = (s == 0 && which == 0) ? gcv[nt] : acc[nt];
     if (PREC)
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[nt][s][pa]),
-                                                       __builtin_bit_cast(f16x8, bf[s & 1][pb]),
-                                                       acc[nt], 0, 0, 0);
+                                                       __builtin_bit_cast(f16x8, bf[s % NB][pb]),
+                                                       c, 0, 0, 0);
     else
-      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][s][pa], bf[s & 1][pb], acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][s][pa], bf[s % NB][pb], c, 0, 0, 0);
   };
-  auto init_acc = [&](f32x16 (&acc)[NT]) {
+  auto load_b_head = [&](const uint4 *bt) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const float4 *g4 = reinterpret_cast<const float4 *>(&s_gc[nt * 32 + h * 16]);
+    for (int s = 0; s < kPre && s < KS; ++s) load_b(bt, s);
+  };
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        float4 v = g4[q4];
-        acc[nt][4 * q4 + 0] = v.x;
-        acc[nt][4 * q4 + 1] = v.y;
-        acc[nt][4 * q4 + 2] = v.z;
-        acc[nt][4 * q4 + 3] = v.w;
-      }
+  for (int nt = 0; nt < NT; ++nt) {
+    const float4 *g4 = reinterpret_cast<const float4 *>(&s_gc[nt * 32 + h * 16]);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      float4 v = g4[q4];
+      gcv[nt][4 * q4 + 0] = v.x;
+      gcv[nt][4 * q4 + 1] = v.y;
+      gcv[nt][4 * q4 + 2] = v.z;
+      gcv[nt][4 * q4 + 3] = v.w;
     }
-  };
+  }
 
   f32x16 acc_cur[NT];
-  init_acc(acc_cur);
-  load_b(s_b + lane, 0);
+  load_b_head(s_b + lane);
 #pragma unroll
   for (int n = 0; n < kMfma; ++n) mfma_n(acc_cur, s_b + lane, n);
 
   for (int ft = 0; ft < ntile; ++ft) {
     const int t0 = t_begin + (ft << 5);
     const int row = t0 + j;
-    const bool row_ok = (row < t_end) && (h == 0);
     float *orow = ar.out + (size_t)row * ar.ldo;
-    int seg = 0;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+s"(endm[nt]));
 
     const int fn = ft + 1;
     if (fn % FTB == 0 && !(ABL & 16)) {
@@ -750,16 +792,12 @@ __global__ void __launch_bounds__(64 * W, OCC)
     }
     const uint4 *bt = s_b + (((fn / FTB) & 1) * FTB + fn % FTB) * kTileU4 + lane;
     f32x16 acc_next[NT];
-    init_acc(acc_next);
-    if (!(ABL & 8)) load_b(bt, 0);
+    if (!(ABL & 8)) load_b_head(bt);
 
-    // Reference of the segment that starts at register 0 of this frame tile.
-    float R, s_ = 0.0f;
-    {
-      float lo, hi;
-      both_halves(acc_cur[0][0], lo, hi);
-      R = fmaxf(lo, hi) + kRefShift;
-    }
+    // Pass over the registers: matrix instructions of frame tile ft+1 interleaved with
+    // the running sums of tile ft.
+    svec sv;
+    float s_ = 0.0f;
 #pragma unroll
     for (int st = 0; st < kSteps; ++st) {
       const int nt = st >> 4, i = st & 15;
@@ -767,39 +805,70 @@ __global__ void __launch_bounds__(64 * W, OCC)
       for (int n = (max(st - kSkip, 0) * kMfma) / (kSteps - kSkip);
            n < (max(st + 1 - kSkip, 0) * kMfma) / (kSteps - kSkip); ++n)
         mfma_n(acc_next, bt, n);
-      if (ABL & 2) asm volatile("" ::"v"(acc_cur[nt][i]));  // keep the chain alive when timing
-      else s_ += fast_exp2(acc_cur[nt][i] - R);
-      if (((endm[nt] >> i) & 1u) && !(ABL & 4)) {  // wave-uniform: register i closes a pdf segment
-        const int col = __builtin_amdgcn_readlane(colreg, seg);
-        ++seg;
-        float s_lo, s_hi;
-        both_halves(s_, s_lo, s_hi);
-        const float S = s_lo + s_hi;
-        if (col >= 0) {
-          const float v = (R + fast_log2(S)) * kLn2;
-          if (row_ok && !(ABL & 1)) orow[col] = v;
-          if (row_ok && !ABL) {
-            if (!(fabsf(v) <= kMaxAbsLogLike)) {
-              const int k = atomicAdd(ar.ctl, 1);
-              if (k < ar.fix_cap) ar.fix_list[k] = make_int2(row, col);
-            }
+      // Pin the order: without this the compiler gathers all matrix instructions of the
+      // tile in front of the vector work and the two no longer overlap inside the wave.
+#pragma unroll
+      for (int q = 0; q < NT; ++q) pin_order(acc_next[q]);
+      if (ABL & 2) {
+        asm volatile("" ::"v"(acc_cur[nt][i]));
+      } else {
+        const float keep = scalar_bit_as_float(keepm, st);  // does the sum continue into this register?
+        s_ = fmaf(s_, keep, fast_exp2(acc_cur[nt][i]));
+        pin_order(s_);
+      }
+      sv[st] = s_;
+    }
+
+    // Loop over the segments of this wave's chunk, two per iteration: lanes 0-31 finish
+    // segment 2k and lanes 32-63 segment 2k+1 of the same 32 frames.  One
+    // v_permlane32_swap of (value for a, value for b) leaves, in each half-wave, that
+    // half's segment as seen by both halves of the original layout.
+    if (!(ABL & 4)) {
+      int start_a = 0;
+      for (int k = 0; k < npair; ++k) {
+        const int end_a = __builtin_amdgcn_readlane(endreg, 2 * k);
+        const int end_b = __builtin_amdgcn_readlane(endreg, 2 * k + 1);
+        const int col_a = __builtin_amdgcn_readlane(colreg, 2 * k);
+        const int col_b = __builtin_amdgcn_readlane(colreg, 2 * k + 1);
+        const int start_b = min(end_a + 1, kSteps - 1);
+        auto acc_at = [&](int r) {
+          float x = acc_cur[0][r & 15];
+          if (NT == 2) {
+            const float x1 = acc_cur[NT - 1][r & 15];
+            x = r >= 16 ? x1 : x;
           }
-        } else if (col != kColDiscard) {
-          if (row_ok && !(ABL & 1)) {  // parts are merged in natural-log units
+          return x;
+        };
+        const auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(sv[end_a]),
+                                                         __float_as_uint(sv[end_b]), false, false);
+        const auto xx = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_at(start_a)),
+                                                         __float_as_uint(acc_at(start_b)), false, false);
+        // ss[0] / ss[1]: the sums of the even / odd slots; xx[0]: score of the reference
+        // Gaussian (slot 0), xx[1]: first difference (slot 1).
+        const float ref = __uint_as_float(xx[0]);
+        const float S = (1.0f + fast_exp2(__uint_as_float(xx[1]))) +
+                        (__uint_as_float(ss[0]) + __uint_as_float(ss[1]));
+        const int col = h ? col_b : col_a;
+        if (row < t_end) {
+          if (col >= 0) {
+            float v = (ref + fast_log2(S)) * kLn2;
+            if (!(ABL & 1)) orow[col] = v;
+            else pin_order(v);
+            if (!ABL && !(fabsf(v) <= kMaxAbsLogLike)) {
+              const int kk = atomicAdd(ar.ctl, 1);
+              if (kk < ar.fix_cap) ar.fix_list[kk] = make_int2(row, col);
+            }
+          } else if (col != kColDiscard && !(ABL & 1)) {  // parts are merged in natural-log units
             const size_t o = (size_t)(-col - 2) * ar.part_ld + row;
-            ar.part_m[o] = R * kLn2;
+            ar.part_m[o] = ref * kLn2;
             ar.part_s[o] = S;
           }
         }
-        if (st + 1 < kSteps) {
-          float lo, hi;
-          both_halves(acc_cur[(st + 1) >> 4][(st + 1) & 15], lo, hi);
-          R = fmaxf(lo, hi) + kRefShift;
-          s_ = 0.0f;
-        }
+        start_a = min(end_b + 1, kSteps - 1);
       }
+    } else {
+      pin_order(sv);
     }
-    if (ABL & 4) asm volatile("" ::"v"(R), "v"(s_));
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc_cur[nt] = acc_next[nt];
   }
@@ -881,7 +950,7 @@ __global__ void gmm_merge_parts_kernel(const SplitPdf *splits, int num_splits,
   const float v = M + kLn2 * fast_log2(S);
   out[(size_t)t * ldo + d.col] = v;
   if (!(fabsf(v) <= kMaxAbsLogLike)) {
-    if (guard == 1) {  // fast path: recompute this pair exactly
+    if (guard == 1) {  // differenced kernel: recompute this pair exactly
       const int k = atomicAdd(ctl, 1);
       if (k < fix_cap) fix_list[k] = make_int2(t, d.col);
     } else {
@@ -998,14 +1067,14 @@ __global__ void __launch_bounds__(256)
 
 typedef void (*ExpandFn)(const float *, int, int, int, uint4 *, int, const float *, int *, int, int);
 struct Variant {
-  int mode;  // 0: exact-fp32 MFMA kernel, 1: bf16x3 kernel, 2: fast kernel (+ bf16x3 fallback)
+  int mode;  // 0: exact-fp32 MFMA kernel, 1: bf16x3 kernel, 3: differenced kernel (+ bf16x3 fallback)
   int D;     // mode 0: feature dimension; mode >= 1: KS = ceil(dim / 8) MFMA k-steps
   int NT, W;
   void (*kernel)(GmmPackView, ScoreArgs);
   ExpandFn expand;  // feature prepass of `kernel`
   const char *name;
-  int prec = 0;  // mode 2: 1 = fp16x2 operands, 0 = bf16x3 operands
-  void (*safe_kernel)(GmmPackView, ScoreArgs) = nullptr;  // mode 2: wide-range / exact fallback
+  int prec = 0;  // mode 3: 1 = fp16x2 operands, 0 = bf16x3 operands
+  void (*safe_kernel)(GmmPackView, ScoreArgs) = nullptr;  // mode 3: wide-range / exact fallback
   ExpandFn safe_expand = nullptr;
 };
 
@@ -1014,16 +1083,16 @@ struct Variant {
 #define AMLIKE_VARIANT_H(KS, NT, W, OCC)                                                  \
   { 1, KS, NT, W, gmm_score_bf16x3_kernel<KS, NT, W, OCC>, gmm_expand_feats_kernel<KS>,   \
     "gmm_score_bf16x3_kernel<" #KS "," #NT "," #W "," #OCC ">" }
-#define AMLIKE_VARIANT_F(KS, NT, W, OCC, PREC)                                               \
-  { 2, KS, NT, W, gmm_score_fast_kernel<KS, NT, W, OCC, PREC>,                                \
+#define AMLIKE_VARIANT_D(KS, NT, W, OCC, PREC)                                               \
+  { 3, KS, NT, W, gmm_score_diff_kernel<KS, NT, W, OCC, PREC>,                                \
     PREC ? gmm_expand_feats_f16_kernel<KS> : gmm_expand_feats_kernel<KS>,                     \
-    PREC ? "gmm_score_fast_kernel<" #KS "," #NT "," #W "," #OCC ",f16x2>"                     \
-         : "gmm_score_fast_kernel<" #KS "," #NT "," #W "," #OCC ",bf16x3>",                   \
+    PREC ? "gmm_score_diff_kernel<" #KS "," #NT "," #W "," #OCC ",f16x2>"                     \
+         : "gmm_score_diff_kernel<" #KS "," #NT "," #W "," #OCC ",bf16x3>",                   \
     PREC, gmm_score_bf16x3_kernel<KS, NT, W, OCC>, gmm_expand_feats_kernel<KS> }
-#define AMLIKE_VARIANT_FABL(KS, NT, W, OCC, PREC, ABL)                                       \
-  { 200 + ABL, KS, NT, W, gmm_score_fast_kernel<KS, NT, W, OCC, PREC, ABL>,                   \
+#define AMLIKE_VARIANT_DABL(KS, NT, W, OCC, PREC, ABL)                                       \
+  { 300 + ABL, KS, NT, W, gmm_score_diff_kernel<KS, NT, W, OCC, PREC, ABL>,                   \
     PREC ? gmm_expand_feats_f16_kernel<KS> : gmm_expand_feats_kernel<KS>,                     \
-    "gmm_score_fast_kernel<" #KS "," #NT "," #W "," #OCC "," #PREC ",ABL=" #ABL ">",          \
+    "gmm_score_diff_kernel<" #KS "," #NT "," #W "," #OCC "," #PREC ",ABL=" #ABL ">",          \
     PREC, gmm_score_bf16x3_kernel<KS, NT, W, OCC>, gmm_expand_feats_kernel<KS> }
 #define AMLIKE_VARIANT_ABL(KS, NT, W, OCC, ABL)                                           \
   { 100 + ABL, KS, NT, W, gmm_score_bf16x3_kernel<KS, NT, W, OCC, ABL>,                   \
@@ -1034,14 +1103,15 @@ struct Variant {
 //         covers every feature dimension up to 64.
 // f32:    exact-fp32 MFMA, NT*D model registers per lane (AMLIKE_GMM_MODE=f32), D = 39 / 40.
 static const Variant kVariants[] = {
-    AMLIKE_VARIANT_F(5, 2, 8, 2, 1), AMLIKE_VARIANT_F(5, 2, 8, 2, 0),
-    AMLIKE_VARIANT_F(1, 2, 8, 2, 1), AMLIKE_VARIANT_F(1, 2, 8, 2, 0),
-    AMLIKE_VARIANT_F(2, 2, 8, 2, 1), AMLIKE_VARIANT_F(2, 2, 8, 2, 0),
-    AMLIKE_VARIANT_F(3, 2, 8, 2, 1), AMLIKE_VARIANT_F(3, 2, 8, 2, 0),
-    AMLIKE_VARIANT_F(4, 2, 8, 2, 1), AMLIKE_VARIANT_F(4, 2, 8, 2, 0),
-    AMLIKE_VARIANT_F(6, 1, 8, 2, 1), AMLIKE_VARIANT_F(6, 1, 8, 2, 0),
-    AMLIKE_VARIANT_F(7, 1, 8, 2, 1), AMLIKE_VARIANT_F(7, 1, 8, 2, 0),
-    AMLIKE_VARIANT_F(8, 1, 8, 2, 1), AMLIKE_VARIANT_F(8, 1, 8, 2, 0),
+    AMLIKE_VARIANT_D(5, 2, 8, 2, 1), AMLIKE_VARIANT_D(5, 2, 8, 2, 0),
+    AMLIKE_VARIANT_D(5, 2, 4, 2, 1), AMLIKE_VARIANT_D(5, 2, 4, 2, 0),
+    AMLIKE_VARIANT_D(1, 2, 8, 2, 1), AMLIKE_VARIANT_D(1, 2, 8, 2, 0),
+    AMLIKE_VARIANT_D(2, 2, 8, 2, 1), AMLIKE_VARIANT_D(2, 2, 8, 2, 0),
+    AMLIKE_VARIANT_D(3, 2, 8, 2, 1), AMLIKE_VARIANT_D(3, 2, 8, 2, 0),
+    AMLIKE_VARIANT_D(4, 2, 8, 2, 1), AMLIKE_VARIANT_D(4, 2, 8, 2, 0),
+    AMLIKE_VARIANT_D(6, 1, 8, 2, 1), AMLIKE_VARIANT_D(6, 1, 8, 2, 0),
+    AMLIKE_VARIANT_D(7, 1, 8, 2, 1), AMLIKE_VARIANT_D(7, 1, 8, 2, 0),
+    AMLIKE_VARIANT_D(8, 1, 8, 2, 1), AMLIKE_VARIANT_D(8, 1, 8, 2, 0),
     AMLIKE_VARIANT_H(5, 2, 8, 2), AMLIKE_VARIANT_H(5, 2, 4, 2),
     AMLIKE_VARIANT_H(1, 2, 8, 2), AMLIKE_VARIANT_H(2, 2, 8, 2), AMLIKE_VARIANT_H(3, 2, 8, 2),
     AMLIKE_VARIANT_H(4, 2, 8, 2), AMLIKE_VARIANT_H(6, 1, 8, 2), AMLIKE_VARIANT_H(7, 1, 8, 2),
@@ -1049,10 +1119,10 @@ static const Variant kVariants[] = {
 #ifdef AMLIKE_ABLATION_BUILD
     AMLIKE_VARIANT_ABL(5, 2, 8, 2, 1), AMLIKE_VARIANT_ABL(5, 2, 8, 2, 6), AMLIKE_VARIANT_ABL(5, 2, 8, 2, 14),
     AMLIKE_VARIANT_ABL(5, 2, 8, 2, 30), AMLIKE_VARIANT_ABL(5, 2, 8, 2, 4),
-    AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 1), AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 2),
-    AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 4), AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 6),
-    AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 14), AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 30),
-    AMLIKE_VARIANT_FABL(5, 2, 8, 2, 1, 8),
+    AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 1), AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 9),
+    AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 2), AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 4),
+    AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 6), AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 14),
+    AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 30), AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 8),
 #endif
     AMLIKE_VARIANT(40, 3, 8), AMLIKE_VARIANT(39, 3, 8),
     AMLIKE_VARIANT(40, 6, 4), AMLIKE_VARIANT(39, 6, 4),
@@ -1076,10 +1146,11 @@ struct amlike_gmm {
   double fill = 0.0;  // used slots / allocated slots
   // device arrays
   void *d_apack = nullptr;
-  void *d_apack_safe = nullptr;  // mode 2 with fp16x2 operands: the bf16x3 image for the fallback
-  float *d_bscale = nullptr;     // mode 2: per k-row feature scale [2][KS * 8]
-  int *d_ctl = nullptr;          // mode 2: {overflow count, range flag}
+  void *d_apack_safe = nullptr;  // differenced kernel: the plain bf16x3 image for the fallback
+  float *d_bscale = nullptr;     // fp16x2 operands: per k-row feature scale [2][KS * 8]
+  int *d_ctl = nullptr;          // differenced kernel: {overflow count, range flag}
   float *d_gcpack = nullptr;
+  float *d_gcpack_safe = nullptr;  // differenced kernels: the plain gconsts for the fallback
   uint32_t *d_endmask = nullptr;
   int32_t *d_segcol = nullptr;
   SplitPdf *d_splits = nullptr;
@@ -1095,7 +1166,7 @@ struct amlike_gmm {
 
 namespace amlike {
 
-// AMLIKE_GMM_MODE = "fast-f16x2" | "fast-bf16x3" | "bf16x3" | "f32" and
+// AMLIKE_GMM_MODE = "diff-f16x2" | "diff-bf16x3" | "bf16x3" | "f32" and
 // AMLIKE_GMM_VARIANT = "<NT>x<W>" narrow the choice (tuning / A-B aids); by default the
 // first matching entry of kVariants is taken.  f16_ok: the model fits the fp16x2 operands.
 static const Variant *ChooseVariant(int dim, bool f16_ok) {
@@ -1104,11 +1175,11 @@ static const Variant *ChooseVariant(int dim, bool f16_ok) {
   for (const Variant &v : kVariants) {
     if (v.mode == 0 && v.D != dim) continue;
     if (v.mode >= 1 && v.D != (dim + 7) / 8) continue;
-    if ((v.mode == 2 || v.mode >= 200) && v.prec == 1 && !f16_ok) continue;
-    const char *vname = v.mode == 0 ? "f32" : v.mode == 1 ? "bf16x3" : v.prec ? "fast-f16x2" : "fast-bf16x3";
-    if (v.mode >= 100) {  // ablation instantiations: only by explicit request "abl<N>" / "fabl<N>"
+    if ((v.mode == 3 || v.mode >= 300) && v.prec == 1 && !f16_ok) continue;
+    const char *vname = v.mode == 0 ? "f32" : v.mode == 1 ? "bf16x3" : (v.prec ? "diff-f16x2" : "diff-bf16x3");
+    if (v.mode >= 100) {  // ablation instantiations: only by explicit request "abl<N>" / "dabl<N>"
       char want[32];
-      if (v.mode >= 200) snprintf(want, sizeof(want), "fabl%d", v.mode - 200);
+      if (v.mode >= 300) snprintf(want, sizeof(want), "dabl%d", v.mode - 300);
       else snprintf(want, sizeof(want), "abl%d", v.mode - 100);
       if (!mode || strcmp(mode, want) != 0) continue;
     } else if (mode && strcmp(mode, vname) != 0) {
@@ -1156,31 +1227,24 @@ static inline void SplitF16x2(float x, uint16_t p[2]) {
 }
 
 // Chooses, for every k-row of the contraction (kind 0: miv_d * x_d, kind 1: -0.5 iv_d * x_d^2),
-// a power-of-two scale that balances the largest model value against the largest feature value
-// the model itself makes plausible (|mean| + 8 sigma over all Gaussians), so that both operands
-// of the fp16x2 kernel stay far from the ends of the fp16 range.  Returns false when some row
-// cannot be balanced into [0, 16384]: the model then runs on the bf16x3 operands.
-static bool ComputeF16Scales(const float *gconsts, const float *miv, const float *iv, int G, int D,
+// a power-of-two scale that balances the largest model value `amax` (already in log2 units)
+// against the largest feature value the model itself makes plausible (xr_d = |mean| + 8 sigma
+// over all Gaussians), so that both operands of the fp16x2 kernels stay far from the ends of
+// the fp16 range.  Returns false when some row cannot be balanced into [0, 16384]: the model
+// then runs on the bf16x3 operands.
+static bool ComputeF16Scales(const std::vector<double> &amax, const std::vector<double> &xr, int D,
                              int KS, std::vector<float> *ascale, std::vector<float> *bscale) {
   ascale->assign((size_t)2 * KS * 8, 1.0f);
   bscale->assign((size_t)2 * KS * 8, 1.0f);
   for (int d = 0; d < D; ++d) {
-    double amax[2] = {0.0, 0.0}, xr = 0.0;
-    for (int g = 0; g < G; ++g) {
-      if (!std::isfinite(gconsts[g])) continue;
-      const double v = iv[(size_t)g * D + d], m = miv[(size_t)g * D + d];
-      if (!(v > 0.0) || !std::isfinite(v) || !std::isfinite(m)) return false;
-      amax[0] = std::max(amax[0], std::fabs(m) * kLog2e);
-      amax[1] = std::max(amax[1], 0.5 * v * kLog2e);
-      xr = std::max(xr, std::fabs(m / v) + 8.0 / std::sqrt(v));
-    }
     for (int kind = 0; kind < 2; ++kind) {
-      const double bmax = kind ? xr * xr : xr;
+      const double a = amax[(size_t)kind * D + d];
+      const double bmax = kind ? xr[d] * xr[d] : xr[d];
+      if (!std::isfinite(a) || !std::isfinite(bmax)) return false;
       int e = 0;
-      if (amax[kind] > 0.0 && bmax > 0.0)
-        e = (int)std::lround(0.5 * (std::log2(bmax) - std::log2(amax[kind])));
+      if (a > 0.0 && bmax > 0.0) e = (int)std::lround(0.5 * (std::log2(bmax) - std::log2(a)));
       e = std::max(-60, std::min(60, e));
-      if (std::ldexp(amax[kind], e) > 16384.0 || std::ldexp(bmax, -e) > 16384.0) return false;
+      if (std::ldexp(a, e) > 16384.0 || std::ldexp(bmax, -e) > 16384.0) return false;
       (*ascale)[(size_t)kind * KS * 8 + d] = std::ldexp(1.0f, e);
       (*bscale)[(size_t)kind * KS * 8 + d] = std::ldexp(1.0f, -e);
     }
@@ -1188,7 +1252,14 @@ static bool ComputeF16Scales(const float *gconsts, const float *miv, const float
   return true;
 }
 
-// Packs the model for `v`.
+static int Upload(void **dst, const void *src, size_t bytes) {
+  AMLIKE_HIP(hipMalloc(dst, bytes));
+  AMLIKE_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return AMLIKE_OK;
+}
+
+// Packs the model for g->variant (and may replace g->variant by its bf16x3 twin when the
+// model does not fit the fp16x2 operands).
 //
 // A wave-chunk is NT tiles x 32 slots.  Every pdf takes an even number of
 // consecutive slots (odd sizes get one slot with gconst = -inf), so that a pdf
@@ -1198,13 +1269,16 @@ static bool ComputeF16Scales(const float *gconsts, const float *miv, const float
 // pdfs are laid out in order; when the next one does not fit in what is left
 // of a chunk, a short look-ahead picks a later one that does.  A pdf larger
 // than a whole chunk is cut into parts whose (max,sum) are merged afterwards.
+//
+// Within a pdf (or part) the live Gaussians come first, broadest first, then the disabled
+// ones (gconst = -inf).  The differenced kernels get a second image in which slot 0 of
+// every part keeps the first Gaussian as it is and every other slot holds
+// (Gaussian - first Gaussian), gconst and operands alike.
 static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, const float *iv,
-                     const int32_t *offs, const std::vector<float> &ascale,
-                     const std::vector<float> &bscale) {
-  const Variant &v = *g->variant;
-  const bool fast = v.mode == 2 || v.mode >= 200;
-  const bool f16 = fast && v.prec == 1;
-  const int D = g->dim, NT = v.NT, W = v.W, DQ = (D + 3) / 4, KS = (D + 7) / 8;
+                     const int32_t *offs) {
+  const Variant *vp = g->variant;
+  const int D = g->dim, NT = vp->NT, W = vp->W, DQ = (D + 3) / 4, KS = (D + 7) / 8;
+  const int vmode = vp->mode >= 300 ? 3 : vp->mode >= 100 ? 1 : vp->mode;
   const int cap = NT * 32;
   std::vector<Piece> pieces;
   std::vector<SplitPdf> splits;
@@ -1227,6 +1301,82 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
       splits.push_back(sp);
     }
   }
+  // Order of the Gaussians inside each piece (index = g_begin + position).
+  std::vector<float> logdet(g->num_gauss);  // sum_d log(inv var): smaller = broader
+  for (int gi = 0; gi < g->num_gauss; ++gi) {
+    double acc = 0.0;
+    for (int d = 0; d < D; ++d) acc += std::log(std::max(iv[(size_t)gi * D + d], 1e-30f));
+    logdet[gi] = (float)acc;
+  }
+  std::vector<int> order(g->num_gauss);
+  for (const Piece &p : pieces) {
+    int lo = 0, hi = p.count;
+    int *o = &order[p.g_begin];
+    for (int q = 0; q < p.count; ++q)
+      if (std::isfinite(gconsts[p.g_begin + q])) o[lo++] = p.g_begin + q;
+    for (int q = p.count - 1; q >= 0; --q)
+      if (!std::isfinite(gconsts[p.g_begin + q])) o[--hi] = p.g_begin + q;
+    std::stable_sort(o, o + lo, [&](int x, int y) { return logdet[x] < logdet[y]; });
+  }
+  // Operand value of Gaussian gi, kind (0: miv, 1: -0.5 iv), dimension d, in log2 units;
+  // `ref` >= 0: differenced against Gaussian ref.  Disabled Gaussians have zero operands.
+  auto opval = [&](int gi, int ref, int kind, int d) -> float {
+    if (!std::isfinite(gconsts[gi])) return 0.0f;
+    auto raw = [&](int x) -> double {
+      return kind ? -0.5 * (double)iv[(size_t)x * D + d] : (double)miv[(size_t)x * D + d];
+    };
+    const double v = ref >= 0 ? raw(gi) - raw(ref) : raw(gi);
+    return (float)(v * (double)kLog2e);
+  };
+  auto gcval = [&](int gi, int ref) -> float {
+    if (!std::isfinite(gconsts[gi])) return kPadGconst;
+    const double v = ref >= 0 ? (double)gconsts[gi] - (double)gconsts[ref] : (double)gconsts[gi];
+    return std::max((float)(v * (double)kLog2e), kPadGconst);
+  };
+  const bool want_diff = vmode == 3;
+  // Slots a piece of `count` Gaussians occupies: an even number; the differenced kernels
+  // want at least two registers (four slots) per segment, because the running sum of a
+  // segment's first register holds the reference's own term and is never read.
+  auto slots_of = [&](int count) { return std::max(want_diff ? 4 : 2, (count + 1) & ~1); };
+  bool f16 = vmode == 3 && vp->prec == 1;
+  std::vector<float> ascale, bscale;
+  if (f16) {
+    std::vector<double> amax((size_t)2 * D, 0.0), xr(D, 0.0);
+    bool ok = true;
+    for (const Piece &p : pieces) {
+      const int ref = order[p.g_begin];
+      for (int q = 0; q < p.count && ok; ++q) {
+        const int gi = order[p.g_begin + q];
+        if (!std::isfinite(gconsts[gi])) continue;
+        for (int d = 0; d < D; ++d) {
+          const double v = iv[(size_t)gi * D + d], m = miv[(size_t)gi * D + d];
+          if (!(v > 0.0) || !std::isfinite(v) || !std::isfinite(m)) {
+            ok = false;
+            break;
+          }
+          xr[d] = std::max(xr[d], std::fabs(m / v) + 8.0 / std::sqrt(v));
+          for (int kind = 0; kind < 2; ++kind) {
+            const float a = opval(gi, (want_diff && q > 0) ? ref : -1, kind, d);
+            amax[(size_t)kind * D + d] = std::max(amax[(size_t)kind * D + d], (double)std::fabs(a));
+          }
+        }
+      }
+    }
+    ok = ok && ComputeF16Scales(amax, xr, D, KS, &ascale, &bscale);
+    if (!ok) {  // same kernel family on bf16x3 operands
+      const Variant *alt = nullptr;
+      for (const Variant &c : kVariants)
+        if (c.mode == vp->mode && c.D == vp->D && c.NT == NT && c.W == W && c.prec == 0) alt = &c;
+      if (!alt) {
+        SetError("amlike_gmm_create: no bf16x3 variant to fall back to");
+        return AMLIKE_EINVAL;
+      }
+      g->variant = vp = alt;
+      f16 = false;
+    }
+  }
+  const Variant &v = *vp;
+
   // Assign pieces to chunks.
   std::vector<std::vector<Piece>> chunks;
   {
@@ -1240,14 +1390,14 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
         while (head < pieces.size() && used[head]) ++head;
         if (head >= pieces.size()) break;
         int pick = -1;
-        const int need_head = (pieces[head].count + 1) & ~1;
+        const int need_head = slots_of(pieces[head].count);
         if (need_head <= left) {
           pick = (int)head;
         } else {
           int best = 0;
           for (size_t k = head + 1; k < pieces.size() && k < head + kLook; ++k) {
             if (used[k]) continue;
-            const int need = (pieces[k].count + 1) & ~1;
+            const int need = slots_of(pieces[k].count);
             if (need <= left && need > best) {
               best = need;
               pick = (int)k;
@@ -1257,7 +1407,7 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
         if (pick < 0) break;
         used[pick] = 1;
         cur.push_back(pieces[pick]);
-        left -= (pieces[pick].count + 1) & ~1;
+        left -= slots_of(pieces[pick].count);
         if (left == 0) break;
       }
       chunks.push_back(cur);
@@ -1272,88 +1422,84 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
   g->num_splits = (int)splits.size();
   g->fill = (double)used_slots / ((double)num_wc * cap);
 
-  // Operand image.  mode 0: fp32 [wc][nt][dq][lane][4]; mode 1: bf16 [wc][nt][s][part][lane][8],
-  // values pre-multiplied by log2(e), lane (r, h): h=0 -> miv, h=1 -> -0.5 iv, d = 8s + jj.
+  // Operand images.  fp32: [wc][nt][dq][lane][4].  16-bit: [wc][nt][s][part][lane][8], lane
+  // (r, h): h = 0 -> miv, h = 1 -> -0.5 iv, d = 8 s + jj, values in log2 units.
+  //   plain image  (apack_h, bf16x3 / apack fp32, with gcpack):  every Gaussian as it is;
+  //   kernel image (apack_k with gcpack_k): what v.kernel reads when that is not the plain
+  //   image: fp16x2 and / or differenced.
+  const bool plain16 = vmode >= 1;
+  const bool kernel_image = f16 || want_diff;
+  const int KP = f16 ? 2 : 3;
   std::vector<float> apack;
-  std::vector<uint16_t> apack_h, apack_f;  // bf16x3 image; fp16x2 image
-  if (v.mode == 0) apack.assign((size_t)num_wc * NT * DQ * 64 * 4, 0.0f);
-  else apack_h.assign((size_t)num_wc * NT * KS * 3 * 64 * 8, 0);
-  if (f16) apack_f.assign((size_t)num_wc * NT * KS * 2 * 64 * 8, 0);
-  // Broadness of a Gaussian: sum_d log(inv var), smaller = broader.
-  std::vector<float> logdet(g->num_gauss);
-  for (int gi = 0; gi < g->num_gauss; ++gi) {
-    double acc = 0.0;
-    for (int d = 0; d < D; ++d) acc += std::log(std::max(iv[(size_t)gi * D + d], 1e-30f));
-    logdet[gi] = (float)acc;
-  }
+  std::vector<uint16_t> apack_h, apack_k;
+  if (vmode == 0) apack.assign((size_t)num_wc * NT * DQ * 64 * 4, 0.0f);
+  if (plain16) apack_h.assign((size_t)num_wc * NT * KS * 3 * 64 * 8, 0);
+  if (kernel_image) apack_k.assign((size_t)num_wc * NT * KS * KP * 64 * 8, 0);
   std::vector<float> gcpack((size_t)num_wc * NT * 32,
-                            v.mode == 0 ? -std::numeric_limits<float>::infinity() : kPadGconst);
+                            vmode == 0 ? -std::numeric_limits<float>::infinity() : kPadGconst);
+  std::vector<float> gcpack_k;
+  if (kernel_image) gcpack_k.assign((size_t)num_wc * NT * 32, kPadGconst);
   std::vector<uint32_t> endmask((size_t)num_wc * NT, 0u);
   std::vector<int32_t> segcol((size_t)num_wc * NT * 16, kColDiscard);
-  std::vector<int> order;
   for (int wc = 0; wc < num_wc; ++wc) {
     int slot = 0, seg = 0;
     for (const Piece &p : chunks[wc]) {
-      // Gaussians with gconst = -inf (zero weight) go last within their pdf, the live ones
-      // broadest first: the first element each half-wave sees of a segment is then a live
-      // one, and the one least likely to be far below the segment's maximum.
-      order.resize(p.count);
-      {
-        int lo = 0, hi = p.count;
-        for (int q = 0; q < p.count; ++q)
-          if (std::isfinite(gconsts[p.g_begin + q])) order[lo++] = p.g_begin + q;
-        for (int q = p.count - 1; q >= 0; --q)
-          if (!std::isfinite(gconsts[p.g_begin + q])) order[--hi] = p.g_begin + q;
-        std::stable_sort(order.begin(), order.begin() + lo,
-                         [&](int x, int y) { return logdet[x] < logdet[y]; });
-      }
+      const int ref = order[p.g_begin];
       for (int q = 0; q < p.count; ++q) {
         const int n = slot + q, nt = n >> 5, nn = n & 31, i = nn >> 1, hh = nn & 1;
         const int r = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const size_t gi = (size_t)order[q];
-        if (v.mode == 0) {
-          gcpack[((size_t)wc * NT + nt) * 32 + hh * 16 + i] = gconsts[gi];
+        const int gi = order[p.g_begin + q];
+        const size_t gcidx = ((size_t)wc * NT + nt) * 32 + hh * 16 + i;
+        if (vmode == 0) {
+          gcpack[gcidx] = gconsts[gi];
           for (int d = 0; d < D; ++d) {
             const size_t base = ((((size_t)wc * NT + nt) * DQ + (d >> 2)) * 64) * 4 + (d & 3);
-            apack[base + (size_t)r * 4] = miv[gi * D + d];
-            apack[base + (size_t)(r + 32) * 4] = -0.5f * iv[gi * D + d];
+            apack[base + (size_t)r * 4] = miv[(size_t)gi * D + d];
+            apack[base + (size_t)(r + 32) * 4] = -0.5f * iv[(size_t)gi * D + d];
           }
-        } else {
-          gcpack[((size_t)wc * NT + nt) * 32 + hh * 16 + i] = std::max(gconsts[gi] * kLog2e, kPadGconst);
-          const bool live = std::isfinite(gconsts[gi]);
-          for (int d = 0; d < D; ++d) {
-            const int s = d >> 3, jj = d & 7;
-            uint16_t pm[3], pv[3];
-            SplitBf16x3(miv[gi * D + d] * kLog2e, pm);
-            SplitBf16x3(-0.5f * iv[gi * D + d] * kLog2e, pv);
-            for (int part = 0; part < 3; ++part) {
-              const size_t base = (((((size_t)wc * NT + nt) * KS + s) * 3 + part) * 64) * 8 + jj;
-              apack_h[base + (size_t)r * 8] = pm[part];
-              apack_h[base + (size_t)(r + 32) * 8] = pv[part];
-            }
-            if (f16 && live) {  // a disabled Gaussian keeps zero operands: its score is the pad gconst
-              uint16_t qm[2], qv[2];
-              SplitF16x2(miv[gi * D + d] * kLog2e * ascale[d], qm);
-              SplitF16x2(-0.5f * iv[gi * D + d] * kLog2e * ascale[(size_t)KS * 8 + d], qv);
-              for (int part = 0; part < 2; ++part) {
-                const size_t base = (((((size_t)wc * NT + nt) * KS + s) * 2 + part) * 64) * 8 + jj;
-                apack_f[base + (size_t)r * 8] = qm[part];
-                apack_f[base + (size_t)(r + 32) * 8] = qv[part];
-              }
-            }
+          continue;
+        }
+        gcpack[gcidx] = std::max(gconsts[gi] * kLog2e, kPadGconst);
+        const int kref = (want_diff && q > 0) ? ref : -1;
+        if (kernel_image) gcpack_k[gcidx] = gcval(gi, kref);
+        for (int d = 0; d < D; ++d) {
+          const int s = d >> 3, jj = d & 7;
+          uint16_t pm[3], pv[3];
+          SplitBf16x3(miv[(size_t)gi * D + d] * kLog2e, pm);
+          SplitBf16x3(-0.5f * iv[(size_t)gi * D + d] * kLog2e, pv);
+          for (int part = 0; part < 3; ++part) {
+            const size_t base = (((((size_t)wc * NT + nt) * KS + s) * 3 + part) * 64) * 8 + jj;
+            apack_h[base + (size_t)r * 8] = pm[part];
+            apack_h[base + (size_t)(r + 32) * 8] = pv[part];
+          }
+          if (!kernel_image) continue;
+          float km = opval(gi, kref, 0, d), kv = opval(gi, kref, 1, d);
+          uint16_t qm[3], qv[3];
+          if (f16) {
+            SplitF16x2(km * ascale[d], qm);
+            SplitF16x2(kv * ascale[(size_t)KS * 8 + d], qv);
+          } else {
+            SplitBf16x3(km, qm);
+            SplitBf16x3(kv, qv);
+          }
+          for (int part = 0; part < KP; ++part) {
+            const size_t base = (((((size_t)wc * NT + nt) * KS + s) * KP + part) * 64) * 8 + jj;
+            apack_k[base + (size_t)r * 8] = qm[part];
+            apack_k[base + (size_t)(r + 32) * 8] = qv[part];
           }
         }
       }
-      slot += (p.count + 1) & ~1;
+      slot += slots_of(p.count);
       const int last_reg = (slot - 2) >> 1;  // register (chunk-wide index) that closes it
       endmask[(size_t)wc * NT + (last_reg >> 4)] |= 1u << (last_reg & 15);
       segcol[(size_t)wc * NT * 16 + seg++] = p.col;
     }
     if (slot < cap) {
-      // Trailing padding: all -inf; it joins the last segment when the chunk is
-      // not empty (the closing bit moves to the chunk's last register), else it
-      // forms one discarded segment.
-      if (seg > 0) {
+      // Trailing padding: all -inf.  The plain kernels let it join the last segment when
+      // the chunk is not empty (the closing bit moves to the chunk's last register); the
+      // differenced kernels keep it as a discarded segment of its own, since its slots
+      // are not differences against that segment's reference.
+      if (seg > 0 && !want_diff) {
         const int last_reg = (slot - 2) >> 1;
         endmask[(size_t)wc * NT + (last_reg >> 4)] &= ~(1u << (last_reg & 15));
       }
@@ -1361,35 +1507,31 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
     }
   }
 
-  if (f16) {
-    AMLIKE_HIP(hipMalloc(&g->d_apack, apack_f.size() * sizeof(uint16_t)));
-    AMLIKE_HIP(hipMemcpy(g->d_apack, apack_f.data(), apack_f.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    AMLIKE_HIP(hipMalloc(&g->d_apack_safe, apack_h.size() * sizeof(uint16_t)));
-    AMLIKE_HIP(hipMemcpy(g->d_apack_safe, apack_h.data(), apack_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    AMLIKE_HIP(hipMalloc(&g->d_bscale, bscale.size() * sizeof(float)));
-    AMLIKE_HIP(hipMemcpy(g->d_bscale, bscale.data(), bscale.size() * sizeof(float), hipMemcpyHostToDevice));
-  } else if (v.mode >= 1) {
-    AMLIKE_HIP(hipMalloc(&g->d_apack, apack_h.size() * sizeof(uint16_t)));
-    AMLIKE_HIP(hipMemcpy(g->d_apack, apack_h.data(), apack_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  int rc = AMLIKE_OK;
+  if (vmode == 0) {
+    rc = Upload(&g->d_apack, apack.data(), apack.size() * sizeof(float));
+    if (rc == AMLIKE_OK) rc = Upload((void **)&g->d_gcpack, gcpack.data(), gcpack.size() * sizeof(float));
+  } else if (kernel_image) {
+    rc = Upload(&g->d_apack, apack_k.data(), apack_k.size() * sizeof(uint16_t));
+    if (rc == AMLIKE_OK) rc = Upload((void **)&g->d_gcpack, gcpack_k.data(), gcpack_k.size() * sizeof(float));
+    if (rc == AMLIKE_OK) rc = Upload(&g->d_apack_safe, apack_h.data(), apack_h.size() * sizeof(uint16_t));
+    if (rc == AMLIKE_OK)
+      rc = Upload((void **)&g->d_gcpack_safe, gcpack.data(), gcpack.size() * sizeof(float));
   } else {
-    AMLIKE_HIP(hipMalloc(&g->d_apack, apack.size() * sizeof(float)));
-    AMLIKE_HIP(hipMemcpy(g->d_apack, apack.data(), apack.size() * sizeof(float), hipMemcpyHostToDevice));
+    rc = Upload(&g->d_apack, apack_h.data(), apack_h.size() * sizeof(uint16_t));
+    if (rc == AMLIKE_OK) rc = Upload((void **)&g->d_gcpack, gcpack.data(), gcpack.size() * sizeof(float));
   }
-  AMLIKE_HIP(hipMalloc(&g->d_gcpack, gcpack.size() * sizeof(float)));
-  AMLIKE_HIP(hipMalloc(&g->d_endmask, endmask.size() * sizeof(uint32_t)));
-  AMLIKE_HIP(hipMalloc(&g->d_segcol, segcol.size() * sizeof(int32_t)));
-  AMLIKE_HIP(hipMemcpy(g->d_gcpack, gcpack.data(), gcpack.size() * sizeof(float), hipMemcpyHostToDevice));
-  AMLIKE_HIP(hipMemcpy(g->d_endmask, endmask.data(), endmask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  AMLIKE_HIP(hipMemcpy(g->d_segcol, segcol.data(), segcol.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (fast) {
+  if (rc == AMLIKE_OK && f16) rc = Upload((void **)&g->d_bscale, bscale.data(), bscale.size() * sizeof(float));
+  if (rc == AMLIKE_OK) rc = Upload((void **)&g->d_endmask, endmask.data(), endmask.size() * sizeof(uint32_t));
+  if (rc == AMLIKE_OK) rc = Upload((void **)&g->d_segcol, segcol.data(), segcol.size() * sizeof(int32_t));
+  if (rc != AMLIKE_OK) return rc;
+  if (vmode == 3) {
     AMLIKE_HIP(hipMalloc(&g->d_ctl, 2 * sizeof(int)));
     AMLIKE_HIP(hipMemset(g->d_ctl, 0, 2 * sizeof(int)));
   }
-  if (!splits.empty()) {
-    AMLIKE_HIP(hipMalloc(&g->d_splits, splits.size() * sizeof(SplitPdf)));
-    AMLIKE_HIP(hipMemcpy(g->d_splits, splits.data(), splits.size() * sizeof(SplitPdf), hipMemcpyHostToDevice));
-  }
-  return AMLIKE_OK;
+  if (!splits.empty())
+    rc = Upload((void **)&g->d_splits, splits.data(), splits.size() * sizeof(SplitPdf));
+  return rc;
 }
 
 // Launches the scoring kernels for [T x dim] device features with conforming layout.
@@ -1435,7 +1577,7 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
   const int KS = v.D, num_ftiles = (T + 31) / 32;
   // One scoring pass: feature prepass (mode >= 1), the kernel, the merge of split pdfs.
   auto pass = [&](void (*kernel)(GmmPackView, ScoreArgs), ExpandFn expand, int parts,
-                  const void *apack, DeviceBuffer *ws, int guard) -> int {
+                  const void *apack, const float *gcp, DeviceBuffer *ws, int guard) -> int {
     size_t smem = 0;
     ScoreArgs a = ar;
     a.guard = guard;
@@ -1455,7 +1597,7 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
         AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
-    GmmPackView pk{apack, g->d_gcpack, g->d_endmask, g->d_segcol, g->num_wc};
+    GmmPackView pk{apack, gcp, g->d_endmask, g->d_segcol, g->num_wc};
     hipLaunchKernelGGL(kernel, dim3(nbx * nby), dim3(64 * v.W), smem, stream, pk, a);
     AMLIKE_HIP(hipGetLastError());
     if (g->num_splits > 0 && v.mode < 100) {
@@ -1466,9 +1608,9 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
     }
     return AMLIKE_OK;
   };
-  if (v.mode == 2 || v.mode >= 200) {
-    // Fast pass, exact repair of the few pairs whose sum overflowed, and a full pass of the
-    // wide-range kernel that runs only when the fast pass could not be used (decided on
+  if (v.mode == 3 || v.mode >= 300) {
+    // Differenced pass, exact repair of the few pairs whose sum overflowed, and a full pass of
+    // the wide-range kernel that runs only when the first pass could not be used (decided on
     // the device: features outside the fp16 range, or more overflows than the list holds).
     const size_t cap = std::max<size_t>(4096, std::min<size_t>((size_t)1 << 21, (size_t)T * g->num_pdfs / 256));
     int rc = g->ws_fix.Reserve(cap * sizeof(int2));
@@ -1476,18 +1618,19 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
     ar.fix_list = static_cast<int2 *>(g->ws_fix.ptr);
     ar.fix_cap = (int)cap;
     AMLIKE_HIP(hipMemsetAsync(g->d_ctl, 0, 2 * sizeof(int), stream));
-    rc = pass(v.kernel, v.expand, v.prec ? 2 : 3, g->d_apack, &g->ws_expand, 1);
+    rc = pass(v.kernel, v.expand, v.prec ? 2 : 3, g->d_apack, g->d_gcpack, &g->ws_expand, 1);
     if (rc != AMLIKE_OK) return rc;
-    if (v.mode >= 200) return AMLIKE_OK;  // timing experiments: the main kernel alone
+    if (v.mode >= 300) return AMLIKE_OK;  // timing experiments: the main kernel alone
     hipLaunchKernelGGL(gmm_fix_kernel, dim3(64), dim3(256), 0, stream, g->d_ctl, ar.fix_list, ar.fix_cap,
                        g->d_gconsts, g->d_miv, g->d_iv, g->d_offsets, g->dim, d_feats, ld, d_out, ldo,
                        g->d_flag);
     AMLIKE_HIP(hipGetLastError());
-    rc = pass(v.safe_kernel, v.safe_expand, 3, v.prec ? g->d_apack_safe : g->d_apack,
+    rc = pass(v.safe_kernel, v.safe_expand, 3, g->d_apack_safe ? g->d_apack_safe : g->d_apack,
+              g->d_gcpack_safe ? g->d_gcpack_safe : g->d_gcpack,
               v.prec ? &g->ws_expand_safe : &g->ws_expand, 2);
     if (rc != AMLIKE_OK) return rc;
   } else {
-    int rc = pass(v.kernel, v.mode >= 1 ? v.expand : nullptr, 3, g->d_apack, &g->ws_expand, 0);
+    int rc = pass(v.kernel, v.mode >= 1 ? v.expand : nullptr, 3, g->d_apack, g->d_gcpack, &g->ws_expand, 0);
     if (rc != AMLIKE_OK) return rc;
   }
   char buf[256];
@@ -1553,10 +1696,7 @@ int amlike_gmm_create(const float *gconsts, const float *means_invvars, const fl
     int rc = amlike_init(0);
     if (rc != AMLIKE_OK) return rc;
   }
-  std::vector<float> ascale, bscale;
-  const bool f16_ok = ComputeF16Scales(gconsts, means_invvars, inv_vars, num_gauss, dim,
-                                       (dim + 7) / 8, &ascale, &bscale);
-  const Variant *v = ChooseVariant(dim, f16_ok);
+  const Variant *v = ChooseVariant(dim, true);  // PackModel may switch to the bf16x3 twin
   if (!v) {
     SetError("amlike_gmm_create: no kernel for feature dimension %d", dim);
     return AMLIKE_EDIM;
@@ -1568,7 +1708,7 @@ int amlike_gmm_create(const float *gconsts, const float *means_invvars, const fl
   g->device = CurrentDevice();
   g->variant = v;
   g->pdf_offsets.assign(pdf_offsets, pdf_offsets + num_pdfs + 1);
-  int rc = PackModel(g, gconsts, means_invvars, inv_vars, pdf_offsets, ascale, bscale);
+  int rc = PackModel(g, gconsts, means_invvars, inv_vars, pdf_offsets);
   if (rc == AMLIKE_OK) {
     auto up = [&](float **dst, const float *src, size_t n) -> int {
       AMLIKE_HIP(hipMalloc(dst, n * sizeof(float)));
@@ -1611,6 +1751,7 @@ int amlike_gmm_destroy(amlike_gmm_t *g) {
   (void)hipFree(g->d_apack);
   (void)hipFree(g->d_apack_safe);
   (void)hipFree(g->d_bscale);
+  (void)hipFree(g->d_gcpack_safe);
   (void)hipFree(g->d_ctl);
   g->ws_expand_safe.Free();
   g->ws_fix.Free();

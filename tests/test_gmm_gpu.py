@@ -53,7 +53,7 @@ def test_both_kernel_families(amlike_device, mode, monkeypatch):
     feats = synth.make_feats(m, 333, seed=72)
     am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
     got = am.LogLikelihoods(feats)
-    assert ("bf16x3" in am.kernel_info()) == (mode == "bf16x3")
+    assert ("gmm_score_bf16x3_kernel" in am.kernel_info()) == (mode == "bf16x3")
     _check(m, feats, got)
 
 
@@ -203,3 +203,74 @@ def test_log_sum_exp_prune(amlike_device, prune):
         f = per_gauss[t, off[p]:off[p + 1]]
         cutoff = f.max() - prune
         assert np.abs(f - cutoff).min() < 1e-3, "entry (%d,%d) differs away from the cutoff" % (t, p)
+
+
+@pytest.mark.parametrize("mode", ["diff-f16x2", "diff-bf16x3"])
+def test_differenced_kernel_operand_types(amlike_device, mode, monkeypatch):
+    monkeypatch.setenv("AMLIKE_GMM_MODE", mode)
+    m = synth.make_gmm(40, 120, 2500, seed=71)
+    feats = synth.make_feats(m, 333, seed=72)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    got = am.LogLikelihoods(feats)
+    assert "gmm_score_diff_kernel" in am.kernel_info()
+    assert ("f16x2" in am.kernel_info()) == (mode == "diff-f16x2")
+    _check(m, feats, got)
+
+
+def test_sum_overflow_is_repaired_exactly(amlike_device):
+    """A narrow Gaussian that beats the pdf's broadest one by more than 2^128 overflows the
+    reference-relative sum of the default kernel; those (frame, pdf) pairs are recomputed."""
+    rng = np.random.default_rng(5)
+    D, P = 40, 12
+    per = 6
+    G = P * per
+    means = rng.standard_normal((G, D)).astype(np.float32)
+    var = np.full((G, D), 100.0, np.float32)
+    var[1::per] = 0.01  # second Gaussian of every pdf: very narrow
+    w = np.full(G, 1.0 / per, np.float32)
+    iv = (1.0 / var).astype(np.float32)
+    m = dict(weights=w, inv_vars=iv, means_invvars=(means * iv).astype(np.float32),
+             pdf_offsets=np.arange(0, G + 1, per, dtype=np.int32), dim=D)
+    feats = (rng.standard_normal((64, D)) * 3).astype(np.float32)
+    feats[::4] = means[1::per][rng.integers(0, P, 16)]  # frames sitting on narrow Gaussians
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    got = am.LogLikelihoods(feats)
+    assert "gmm_score_diff_kernel" in am.kernel_info()
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    per_gauss = oracle.diag_gmm_loglikes_mat(gc, m["means_invvars"], m["inv_vars"], feats)
+    spread = per_gauss.reshape(64, P, per).max(2) - per_gauss.reshape(64, P, per)[:, :, 0]
+    assert (spread > 100).any()  # the case is really exercised (100 nats > 2^128)
+    want, st = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"], feats)
+    assert st == 0
+    assert np.abs(got - want).max() <= TOL * max(1.0, np.abs(want).max() / 1000)
+
+
+def test_features_outside_fp16_range_use_the_wide_range_kernel(amlike_device):
+    m = synth.make_gmm(40, 30, 400, seed=93)
+    feats = synth.make_feats(m, 96, seed=94)
+    feats[17, 3] = 3.0e4   # x^2 = 9e8: far outside the scaled fp16 operand range
+    feats[40, :] *= 2000.0
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    got = am.LogLikelihoods(feats)
+    assert "f16x2" in am.kernel_info()
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    want, st = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"], feats)
+    assert st == 0 and np.isfinite(got).all()
+    # scores of the outlier frames are ~1e9 in magnitude: compare relatively there
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=TOL)
+    ok = np.ones(96, bool)
+    ok[[17, 40]] = False
+    assert np.abs(got[ok] - want[ok]).max() <= TOL
+
+
+def test_model_outside_fp16_range_uses_bf16x3_operands(amlike_device):
+    m = synth.make_gmm(24, 20, 200, seed=95)
+    m["inv_vars"][5, 2] = 3.0e7          # a variance of 3e-8: cannot be balanced into fp16
+    m["means_invvars"][5, 2] = 1.0e7
+    feats = synth.make_feats(m, 50, seed=96)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    got = am.LogLikelihoods(feats)
+    assert "gmm_score_diff_kernel" in am.kernel_info() and "bf16x3" in am.kernel_info()
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    want, _ = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"], feats)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=TOL)
