@@ -157,6 +157,16 @@ def main():
         peak = FP32_MFMA_PEAK_TFLOPS
         peak_basis = "fp32 MFMA dense peak"
 
+    # HBM traffic of the dominant kernel per launch, from rocprofv3 PMC passes of this same
+    # workload (FETCH_SIZE and WRITE_SIZE collected in separate runs; FETCH_SIZE doubled, the
+    # gfx950 correction for 16-byte-per-lane loads).  Only valid for that kernel and shape.
+    traffic = None
+    if args.config == "swbd_tri4" and "gmm_score_diff_kernel<5,2,8,2,f16x2>" in am.kernel_info() \
+            and T == 35554:
+        traffic = {"bytes": 2.0 * 686038e3 + 1257140e3, "fetch_bytes": 2.0 * 686038e3,
+                   "write_bytes": 1257140e3, "algorithmic_bytes": 4.0 * T * P + 4.0 * T * D,
+                   "source": "profiles/r1_d_gmm_diff_pmc_summary.txt"}
+
     if rank == 0:
         value = tot_frames * args.steps / elapsed
         line = {
@@ -174,7 +184,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": peak,
-                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "kernel_ms": ms, "flop_per_frame": flop_per_frame,
                 "peak_basis": peak_basis,
                 "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
