@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <string>
 
 #include "../../include/amlike.h"
@@ -27,6 +29,29 @@ struct DeviceBuffer {
   int Reserve(size_t want);  // AMLIKE_OK / AMLIKE_EOOM
   void Free();
 };
+
+// fp32 -> bf16, round to nearest even (inf / nan: truncated).
+static inline uint16_t Bf16Rne(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float Bf16ToFloat(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float x;
+  memcpy(&x, &u, 4);
+  return x;
+}
+// x = p[0] + p[1] + p[2] exactly (24 mantissa bits over three bf16).
+static inline void SplitBf16x3(float x, uint16_t p[3]) {
+  p[0] = Bf16Rne(x);
+  float r = x - Bf16ToFloat(p[0]);
+  p[1] = Bf16Rne(r);
+  r -= Bf16ToFloat(p[1]);
+  p[2] = Bf16Rne(r);
+}
 
 }  // namespace amlike
 

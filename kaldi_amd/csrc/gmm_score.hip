@@ -1195,29 +1195,6 @@ static const Variant *ChooseVariant(int dim, bool f16_ok) {
   return nullptr;
 }
 
-// fp32 -> bf16, round to nearest even (finite inputs; the model has no NaN here).
-static inline uint16_t Bf16Rne(float x) {
-  uint32_t u;
-  memcpy(&u, &x, 4);
-  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);  // inf / nan: truncate
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-static inline float Bf16ToFloat(uint16_t b) {
-  uint32_t u = (uint32_t)b << 16;
-  float x;
-  memcpy(&x, &u, 4);
-  return x;
-}
-// x = p[0] + p[1] + p[2] exactly (24 mantissa bits over three bf16).
-static inline void SplitBf16x3(float x, uint16_t p[3]) {
-  p[0] = Bf16Rne(x);
-  float r = x - Bf16ToFloat(p[0]);
-  p[1] = Bf16Rne(r);
-  r -= Bf16ToFloat(p[1]);
-  p[2] = Bf16Rne(r);
-}
-
 // x ~= p[0] + p[1] to 22 bits (two fp16); exact powers of two scale it beforehand.
 static inline void SplitF16x2(float x, uint16_t p[2]) {
   const _Float16 h1 = static_cast<_Float16>(x);

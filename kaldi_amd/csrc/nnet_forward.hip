@@ -14,9 +14,11 @@
 //
 // Kernels (each launch covers ALL frames of a batch of utterances):
 //   nnet_pad_splice_kernel   edge-frame padding + frame splicing in one gather
-//   nnet_gemm_bias_kernel    Y = X W^T + b on v_mfma_f32_32x32x2_f32 (exact fp32, the
-//                            same arithmetic class as the reference's sgemm), 128x128
-//                            block tile, LDS double buffer, one barrier per k-step
+//   nnet_gemm_bias_bf16x3_kernel  Y = X W^T + b on v_mfma_f32_32x32x16_bf16 with bf16x3-split
+//                            operands (fp32-grade results), 128x128 block tile, LDS double
+//                            buffer, one barrier per k-step
+//   nnet_gemm_bias_kernel    the same on v_mfma_f32_32x32x2_f32 (exact fp32 inputs;
+//                            AMLIKE_NNET_GEMM=f32, kept as the A/B check)
 //   nnet_pnorm_norm_kernel   p-norm over groups of consecutive columns, optionally fused
 //                            with the row normalisation that follows it (one HBM pass)
 //   nnet_softmax_kernel      row softmax with the row held in registers (one read), fused
@@ -133,6 +135,141 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
   }
   // Epilogue: bias, store.  Register r of tile (mt, nt): row (r&3) + 8 (r>>2) + 4h, column li.
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n0 + wc * 64 + nt * 32 + li;
+    if (n >= N) continue;
+    const float bv = bias[n];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < M) Y[(size_t)m * ldy + n] = acc[mt][nt][r] + bv;
+      }
+  }
+}
+
+
+// The same product on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the rate of the
+// fp32-input instruction): every fp32 operand is written as the exact sum of three bf16
+// values and a product is accumulated from the six partial products a1b1, a1b2, a2b1,
+// a1b3, a2b2, a3b1 (the three dropped ones are below 2^-24 of the product), which gives
+// fp32-grade results on 6/16 of the fp32 pipe's time.  W arrives pre-split
+// ([3 planes][N][Kp] bf16, Kp a multiple of 16, zero padded); X is fp32 and is split
+// while its tile is staged into LDS.
+//
+// 256 threads = 4 waves in a 2 x 2 arrangement, each wave a 64 x 64 tile = 2 x 2 MFMA tiles;
+// k-step 16.  LDS tiles are [plane][block of 32 rows][k-octet][32 rows] x 16 bytes, i.e.
+// exactly the order in which the 64 lanes of a wave read an MFMA operand (lane (r, h): 8
+// consecutive k, octet h, of row r): ds_read_b128 at base + lane, conflict-free.
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+
+// Two floats -> three words of packed bf16 pairs (first, second, third term of each).
+__device__ __forceinline__ void split_bf16x3_2(float a, float b, unsigned &o1, unsigned &o2,
+                                               unsigned &o3) {
+  const __bf16 a1 = static_cast<__bf16>(a), b1 = static_cast<__bf16>(b);
+  const float ra = a - static_cast<float>(a1), rb = b - static_cast<float>(b1);
+  const __bf16 a2 = static_cast<__bf16>(ra), b2 = static_cast<__bf16>(rb);
+  const float sa = ra - static_cast<float>(a2), sb = rb - static_cast<float>(b2);
+  const __bf16 a3 = static_cast<__bf16>(sa), b3 = static_cast<__bf16>(sb);
+  o1 = __builtin_bit_cast(unsigned short, a1) | (unsigned)__builtin_bit_cast(unsigned short, b1) << 16;
+  o2 = __builtin_bit_cast(unsigned short, a2) | (unsigned)__builtin_bit_cast(unsigned short, b2) << 16;
+  o3 = __builtin_bit_cast(unsigned short, a3) | (unsigned)__builtin_bit_cast(unsigned short, b3) << 16;
+}
+__device__ __forceinline__ void split_bf16x3_8(const float4 &lo, const float4 &hi, uint4 &o1,
+                                               uint4 &o2, uint4 &o3) {
+  split_bf16x3_2(lo.x, lo.y, o1.x, o2.x, o3.x);
+  split_bf16x3_2(lo.z, lo.w, o1.y, o2.y, o3.y);
+  split_bf16x3_2(hi.x, hi.y, o1.z, o2.z, o3.z);
+  split_bf16x3_2(hi.z, hi.w, o1.w, o2.w, o3.w);
+}
+
+__global__ void __launch_bounds__(256, 2)
+    nnet_gemm_bias_bf16x3_kernel(const float *__restrict__ X, int ldx,
+                                 const uint4 *__restrict__ Wp, int Kp,
+                                 const float *__restrict__ bias, float *__restrict__ Y, int ldy,
+                                 int M, int N) {
+  // [buf][plane][row block][octet][32] : 2 * 3 * 4 * 2 * 32 * 16 B = 24 KiB per operand
+  __shared__ __attribute__((aligned(16))) uint4 s_x[2][3][4][2][32];
+  __shared__ __attribute__((aligned(16))) uint4 s_w[2][3][4][2][32];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = w >> 1, wc = w & 1, li = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  // Staging assignment: wave w stages row block w of both operands; lane (li, h) -> row li,
+  // octet h.
+  const int srow = w * 32 + li;
+  const float4 *xa = reinterpret_cast<const float4 *>(X + (size_t)min(m0 + srow, M - 1) * ldx) + 2 * h;
+  const size_t wrow = (size_t)min(n0 + srow, N - 1) * (Kp >> 3) + h;  // in uint4 units
+  const size_t wplane = (size_t)N * (Kp >> 3);
+  const int nk = Kp >> 4;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  float4 rx0 = xa[0], rx1 = xa[1];
+  uint4 rw0 = Wp[wrow], rw1 = Wp[wplane + wrow], rw2 = Wp[2 * wplane + wrow];
+  {
+    uint4 sx0, sx1, sx2;
+    split_bf16x3_8(rx0, rx1, sx0, sx1, sx2);
+    s_x[0][0][w][h][li] = sx0;
+    s_x[0][1][w][h][li] = sx1;
+    s_x[0][2][w][h][li] = sx2;
+    s_w[0][0][w][h][li] = rw0;
+    s_w[0][1][w][h][li] = rw1;
+    s_w[0][2][w][h][li] = rw2;
+  }
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) {
+      rx0 = xa[(ks + 1) * 4];
+      rx1 = xa[(ks + 1) * 4 + 1];
+      const size_t o = wrow + (size_t)(ks + 1) * 2;
+      rw0 = Wp[o];
+      rw1 = Wp[wplane + o];
+      rw2 = Wp[2 * wplane + o];
+    }
+    bf16x8_t fa[2][3], fb[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        fa[mt][q] = __builtin_bit_cast(bf16x8_t, s_x[cur][q][wr * 2 + mt][h][li]);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        fb[nt][q] = __builtin_bit_cast(bf16x8_t, s_w[cur][q][wc * 2 + nt][h][li]);
+    // small terms first; the four accumulators alternate so that consecutive matrix
+    // instructions are independent
+#pragma unroll
+    for (int which = 0; which < 6; ++which) {
+      const int pa = which == 0 ? 2 : (which == 1 || which == 3) ? 1 : 0;
+      const int pb = (which == 0 || which == 3 || which == 5) ? 0 : (which == 1 || which == 4) ? 1 : 2;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][pa], fb[nt][pb], acc[mt][nt], 0, 0, 0);
+    }
+    if (ks + 1 < nk) {
+      uint4 sx0, sx1, sx2;
+      split_bf16x3_8(rx0, rx1, sx0, sx1, sx2);
+      s_x[cur ^ 1][0][w][h][li] = sx0;
+      s_x[cur ^ 1][1][w][h][li] = sx1;
+      s_x[cur ^ 1][2][w][h][li] = sx2;
+      s_w[cur ^ 1][0][w][h][li] = rw0;
+      s_w[cur ^ 1][1][w][h][li] = rw1;
+      s_w[cur ^ 1][2][w][h][li] = rw2;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int n = n0 + wc * 64 + nt * 32 + li;
@@ -405,6 +542,7 @@ struct Stage {
   float p = 2.0f;
   int normalize_after = 0;  // pnorm fused with the Normalize that follows
   float *d_w = nullptr;     // [out_dim][Kp]
+  uint4 *d_wp = nullptr;    // the same split into bf16 planes: [3][out_dim][Kp] bf16
   float *d_bias = nullptr;
   int Kp = 0;
   int32_t *d_begins = nullptr;  // sumgroup prefix [out_dim + 1]
@@ -418,6 +556,7 @@ struct amlike_nnet {
   std::vector<Stage> stages;  // after fusion
   int input_dim = 0, output_dim = 0, left = 0, right = 0;
   int num_priors = 0;
+  bool gemm_f32 = false;  // AMLIKE_NNET_GEMM=f32: the exact-fp32 MFMA GEMM (A/B check of the bf16x3 one)
   float *d_log_priors = nullptr;
   hipStream_t stream = nullptr;
   DeviceBuffer ws_a, ws_b, ws_in, ws_out, ws_utts;
@@ -430,6 +569,7 @@ namespace amlike {
 static void FreeNnet(amlike_nnet *n) {
   for (Stage &s : n->stages) {
     (void)hipFree(s.d_w);
+    (void)hipFree(s.d_wp);
     (void)hipFree(s.d_bias);
     (void)hipFree(s.d_begins);
   }
@@ -481,8 +621,8 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
   }
   // Worst-case activation buffer: rows (with padding) x widest stage.
   int64_t max_rows = in_total + (int64_t)num_utts * (pad_l + pad_r);
-  int max_ld = RoundUp(n->input_dim, 8);
-  for (const Stage &s : n->stages) max_ld = std::max(max_ld, RoundUp(s.out_dim, 8));
+  int max_ld = RoundUp(n->input_dim, 16);
+  for (const Stage &s : n->stages) max_ld = std::max(max_ld, RoundUp(s.out_dim, 16));
   int rc = n->ws_a.Reserve((size_t)max_rows * max_ld * sizeof(float));
   if (rc != AMLIKE_OK) return rc;
   rc = n->ws_b.Reserve((size_t)max_rows * max_ld * sizeof(float));
@@ -554,7 +694,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
   };
   if (copy_first) {
     float *dst = bufs[which];
-    const int dst_ld = RoundUp(n->input_dim, 8);
+    const int dst_ld = RoundUp(n->input_dim, 16);
     rc = launch_gather(0, 1, n->input_dim, 0, dst, dst_ld, n->input_dim);
     if (rc != AMLIKE_OK) return rc;
     cur = dst;
@@ -567,7 +707,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
     const bool last = (si + 1 == ns);
     const int spost = last ? post : 0;
     float *dst = last ? d_out : bufs[which];
-    const int dst_ld = last ? ldo : RoundUp(s.out_dim, 8);
+    const int dst_ld = last ? ldo : RoundUp(s.out_dim, 16);
     const int zero_pad = last ? 0 : 1;
     int64_t out_rows = cur_rows;
     if (s.kind == AMLIKE_SPLICE) {
@@ -588,8 +728,12 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         return AMLIKE_EINVAL;
       }
       dim3 grid((s.out_dim + 127) / 128, (unsigned)((cur_rows + 127) / 128));
-      hipLaunchKernelGGL(nnet_gemm_bias_kernel, grid, dim3(256), 0, st, cur, cur_ld, s.d_w, s.Kp,
-                         s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
+      if (n->gemm_f32)
+        hipLaunchKernelGGL(nnet_gemm_bias_kernel, grid, dim3(256), 0, st, cur, cur_ld, s.d_w, s.Kp,
+                           s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
+      else
+        hipLaunchKernelGGL(nnet_gemm_bias_bf16x3_kernel, grid, dim3(256), 0, st, cur, cur_ld, s.d_wp,
+                           s.Kp, s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
       AMLIKE_HIP(hipGetLastError());
       if (!last && dst_ld != s.out_dim) {
         hipLaunchKernelGGL(nnet_zero_pad_kernel, dim3(256), dim3(256), 0, st, dst, (int)cur_rows,
@@ -667,6 +811,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
     if (rc != AMLIKE_OK) return rc;
   }
   amlike_nnet *n = new amlike_nnet;
+  if (const char *e = getenv("AMLIKE_NNET_GEMM")) n->gemm_f32 = strcmp(e, "f32") == 0;
   n->input_dim = comps[0].input_dim;
   int dim = comps[0].input_dim;
   int rc = AMLIKE_OK;
@@ -703,12 +848,21 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
           rc = AMLIKE_EINVAL;
           break;
         }
-        s.Kp = RoundUp(c.input_dim, 8);
+        s.Kp = RoundUp(c.input_dim, 16);
         std::vector<float> w((size_t)c.output_dim * s.Kp, 0.0f);
         for (int r = 0; r < c.output_dim; ++r)
           memcpy(&w[(size_t)r * s.Kp], c.linear + (size_t)r * c.input_dim, c.input_dim * sizeof(float));
+        std::vector<uint16_t> wp(3 * w.size());
+        for (size_t idx = 0; idx < w.size(); ++idx) {
+          uint16_t parts[3];
+          SplitBf16x3(w[idx], parts);
+          for (int q = 0; q < 3; ++q) wp[q * w.size() + idx] = parts[q];
+        }
         hipError_t e = hipMalloc(&s.d_w, w.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(s.d_w, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(&s.d_wp, wp.size() * sizeof(uint16_t));
+        if (e == hipSuccess)
+          e = hipMemcpy(s.d_wp, wp.data(), wp.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc(&s.d_bias, c.output_dim * sizeof(float));
         if (e == hipSuccess)
           e = hipMemcpy(s.d_bias, c.bias, c.output_dim * sizeof(float), hipMemcpyHostToDevice);
@@ -764,6 +918,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
     }
     if (rc != AMLIKE_OK) {
       (void)hipFree(s.d_w);
+      (void)hipFree(s.d_wp);
       (void)hipFree(s.d_bias);
       (void)hipFree(s.d_begins);
       break;

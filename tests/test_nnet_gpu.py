@@ -93,3 +93,21 @@ def test_errors(amlike_device):
     with pytest.raises(_lib.AmlikeError) as e:
         nnet.AmNnet(comps, priors[:50]).Compute(np.zeros((20, 13), np.float32), mode=nnet.LOGLIKES)
     assert "Priors" in str(e.value)
+
+
+def test_exact_fp32_gemm_gives_the_same_answers(amlike_device, monkeypatch):
+    """AMLIKE_NNET_GEMM=f32 selects the exact-fp32 MFMA GEMM; the default bf16x3 GEMM must
+    agree with it (and with the oracle) to fp32 rounding."""
+    comps, priors = synth.make_pnorm_nnet(input_dim=40, left=4, right=4, hidden=300, pnorm_out=60,
+                                          num_hidden=2, num_pdfs=500, mix_up=0, seed=61)
+    feats = np.random.default_rng(62).standard_normal((150, 40)).astype(np.float32) * 3.0
+    outs = {}
+    for gemm in ("bf16x3", "f32"):
+        monkeypatch.setenv("AMLIKE_NNET_GEMM", gemm)
+        net = nnet.AmNnet(comps, priors)
+        outs[gemm] = net.Compute(feats, pad_input=True, mode=nnet.LOGLIKES, prob_scale=1.0)
+        net.close()
+    want = oracle.nnet_compute(comps, priors, feats, pad_input=True, mode=2, prob_scale=1.0)
+    assert np.abs(outs["bf16x3"] - outs["f32"]).max() <= 2e-4
+    for o in outs.values():
+        assert np.abs(o - want).max() <= 1e-3
