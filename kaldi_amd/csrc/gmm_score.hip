@@ -1817,23 +1817,39 @@ int amlike_gmm_score(amlike_gmm_t *g, const float *feats, int32_t T, int32_t ld,
   // Bound the device footprint of one pass: at most ~1 GiB of output.
   const int max_t = std::max(1024, (int)std::min<size_t>(1u << 20, ((size_t)1 << 28) / (size_t)P));
   int status = AMLIKE_OK;
+  // Rows travel as one contiguous copy whenever the host layout allows it (a strided
+  // 2-D copy from pageable memory degenerates into one transfer per row); the kernels
+  // take any row stride, so the features keep the caller's ld on the device.
+  const bool feats_1d = (size_t)ld <= (size_t)2 * ldp + 8;
+  const int dld = feats_1d ? ld : ldp;
   for (int t0 = 0; t0 < T; t0 += max_t) {
     const int tn = std::min(max_t, T - t0);
-    rc = g->ws_feats.Reserve((size_t)tn * ldp * sizeof(float));
+    rc = g->ws_feats.Reserve((size_t)tn * dld * sizeof(float));
     if (rc != AMLIKE_OK) return rc;
     rc = g->ws_out.Reserve((size_t)tn * P * sizeof(float));
     if (rc != AMLIKE_OK) return rc;
     float *df = static_cast<float *>(g->ws_feats.ptr);
     float *dout = static_cast<float *>(g->ws_out.ptr);
-    if (ldp != g->dim) AMLIKE_HIP(hipMemsetAsync(df, 0, (size_t)tn * ldp * sizeof(float), g->stream));
-    AMLIKE_HIP(hipMemcpy2DAsync(df, (size_t)ldp * sizeof(float), feats + (size_t)t0 * ld,
-                                (size_t)ld * sizeof(float), (size_t)g->dim * sizeof(float), tn,
-                                hipMemcpyHostToDevice, g->stream));
-    rc = amlike_gmm_score_dev(g, df, tn, ldp, feat_dim, log_sum_exp_prune, dout, P, g->stream);
+    if (feats_1d) {
+      // the last row is only dim wide in the caller's buffer
+      const size_t n = (size_t)(tn - 1) * ld + g->dim;
+      AMLIKE_HIP(hipMemcpyAsync(df, feats + (size_t)t0 * ld, n * sizeof(float), hipMemcpyHostToDevice,
+                                g->stream));
+    } else {
+      AMLIKE_HIP(hipMemcpy2DAsync(df, (size_t)dld * sizeof(float), feats + (size_t)t0 * ld,
+                                  (size_t)ld * sizeof(float), (size_t)g->dim * sizeof(float), tn,
+                                  hipMemcpyHostToDevice, g->stream));
+    }
+    rc = amlike_gmm_score_dev(g, df, tn, dld, feat_dim, log_sum_exp_prune, dout, P, g->stream);
     if (rc != AMLIKE_OK) return rc;
-    AMLIKE_HIP(hipMemcpy2DAsync(out + (size_t)t0 * ldo, (size_t)ldo * sizeof(float), dout,
-                                (size_t)P * sizeof(float), (size_t)P * sizeof(float), tn,
+    if (ldo == P) {
+      AMLIKE_HIP(hipMemcpyAsync(out + (size_t)t0 * ldo, dout, (size_t)tn * P * sizeof(float),
                                 hipMemcpyDeviceToHost, g->stream));
+    } else {
+      AMLIKE_HIP(hipMemcpy2DAsync(out + (size_t)t0 * ldo, (size_t)ldo * sizeof(float), dout,
+                                  (size_t)P * sizeof(float), (size_t)P * sizeof(float), tn,
+                                  hipMemcpyDeviceToHost, g->stream));
+    }
     rc = amlike_gmm_poll(g, g->stream);
     if (rc == AMLIKE_ENONFINITE) status = rc;
     else if (rc != AMLIKE_OK) return rc;
@@ -1886,16 +1902,23 @@ int amlike_gmm_gauss_loglikes(amlike_gmm_t *g, int32_t pdf_begin, int32_t pdf_en
   const int max_t = std::max(64, (int)std::min<size_t>(1u << 20, ((size_t)1 << 28) / (size_t)M));
   for (int t0 = 0; t0 < T; t0 += max_t) {
     const int tn = std::min(max_t, T - t0);
-    int rc = g->ws_feats.Reserve((size_t)tn * feat_dim * sizeof(float));
+    // features: one contiguous copy that keeps the caller's row stride (see amlike_gmm_score)
+    const bool feats_1d = (size_t)ld <= (size_t)2 * feat_dim + 8;
+    const int dld = feats_1d ? ld : feat_dim;
+    int rc = g->ws_feats.Reserve((size_t)tn * dld * sizeof(float));
     if (rc != AMLIKE_OK) return rc;
     rc = g->ws_out.Reserve((size_t)tn * M * sizeof(float));
     if (rc != AMLIKE_OK) return rc;
     float *df = static_cast<float *>(g->ws_feats.ptr);
     float *dout = static_cast<float *>(g->ws_out.ptr);
-    AMLIKE_HIP(hipMemcpy2DAsync(df, (size_t)feat_dim * sizeof(float), feats + (size_t)t0 * ld,
-                                (size_t)ld * sizeof(float), (size_t)feat_dim * sizeof(float), tn,
+    if (feats_1d)
+      AMLIKE_HIP(hipMemcpyAsync(df, feats + (size_t)t0 * ld, ((size_t)(tn - 1) * ld + feat_dim) * sizeof(float),
                                 hipMemcpyHostToDevice, g->stream));
-    rc = amlike_gmm_gauss_loglikes_dev(g, pdf_begin, pdf_end, df, tn, feat_dim, feat_dim, dout, M,
+    else
+      AMLIKE_HIP(hipMemcpy2DAsync(df, (size_t)feat_dim * sizeof(float), feats + (size_t)t0 * ld,
+                                  (size_t)ld * sizeof(float), (size_t)feat_dim * sizeof(float), tn,
+                                  hipMemcpyHostToDevice, g->stream));
+    rc = amlike_gmm_gauss_loglikes_dev(g, pdf_begin, pdf_end, df, tn, dld, feat_dim, dout, M,
                                        g->stream);
     if (rc != AMLIKE_OK) return rc;
     AMLIKE_HIP(hipMemcpy2DAsync(out + (size_t)t0 * ldo, (size_t)ldo * sizeof(float), dout,

@@ -1001,21 +1001,33 @@ int amlike_nnet_compute(amlike_nnet_t *n, const float *feats, int32_t T, int32_t
     SetError("amlike_nnet_compute: %d frames give empty output", T);
     return AMLIKE_EINVAL;
   }
-  int rc = n->ws_in.Reserve((size_t)T * n->input_dim * sizeof(float));
+  // Features travel as one contiguous copy that keeps the caller's row stride (a strided
+  // 2-D copy from pageable memory degenerates into one transfer per 160-byte row).
+  const bool feats_1d = (size_t)ld <= (size_t)2 * n->input_dim + 8;
+  const int dld = feats_1d ? ld : n->input_dim;
+  int rc = n->ws_in.Reserve((size_t)T * dld * sizeof(float));
   if (rc != AMLIKE_OK) return rc;
   rc = n->ws_out.Reserve((size_t)t_out * n->output_dim * sizeof(float));
   if (rc != AMLIKE_OK) return rc;
   float *din = static_cast<float *>(n->ws_in.ptr), *dout = static_cast<float *>(n->ws_out.ptr);
-  AMLIKE_HIP(hipMemcpy2DAsync(din, (size_t)n->input_dim * sizeof(float), feats,
-                              (size_t)ld * sizeof(float), (size_t)n->input_dim * sizeof(float), T,
+  if (feats_1d)
+    AMLIKE_HIP(hipMemcpyAsync(din, feats, ((size_t)(T - 1) * ld + n->input_dim) * sizeof(float),
                               hipMemcpyHostToDevice, n->stream));
-  rc = amlike_nnet_compute_dev(n, din, T, n->input_dim, pad_input, mode, prob_scale, dout,
+  else
+    AMLIKE_HIP(hipMemcpy2DAsync(din, (size_t)n->input_dim * sizeof(float), feats,
+                                (size_t)ld * sizeof(float), (size_t)n->input_dim * sizeof(float), T,
+                                hipMemcpyHostToDevice, n->stream));
+  rc = amlike_nnet_compute_dev(n, din, T, dld, pad_input, mode, prob_scale, dout,
                                n->output_dim, n->stream);
   if (rc != AMLIKE_OK) return rc;
-  AMLIKE_HIP(hipMemcpy2DAsync(out, (size_t)ldo * sizeof(float), dout,
-                              (size_t)n->output_dim * sizeof(float),
-                              (size_t)n->output_dim * sizeof(float), t_out, hipMemcpyDeviceToHost,
-                              n->stream));
+  if (ldo == n->output_dim)
+    AMLIKE_HIP(hipMemcpyAsync(out, dout, (size_t)t_out * n->output_dim * sizeof(float),
+                              hipMemcpyDeviceToHost, n->stream));
+  else
+    AMLIKE_HIP(hipMemcpy2DAsync(out, (size_t)ldo * sizeof(float), dout,
+                                (size_t)n->output_dim * sizeof(float),
+                                (size_t)n->output_dim * sizeof(float), t_out, hipMemcpyDeviceToHost,
+                                n->stream));
   AMLIKE_HIP(hipStreamSynchronize(n->stream));
   return AMLIKE_OK;
 }
