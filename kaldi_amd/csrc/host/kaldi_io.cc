@@ -256,13 +256,62 @@ void Matrix::Swap(Matrix *o) {
   data_.swap(o->data_);
 }
 
+// CompressedMatrix on disk (matrix/compressed-matrix.cc:404-470): after the token, a header
+// {float min_value, float range, int32 num_rows, int32 num_cols}; then
+//   "CM"  (format 1): num_cols x {uint16 p0, p25, p75, p100}, then num_cols columns of
+//         num_rows bytes; a byte maps piecewise-linearly between the column's percentiles
+//         (CharToFloat :363-373);
+//   "CM2" (format 2): num_rows x num_cols uint16, row-major.
+// A uint16 u stands for min_value + range * u / 65535 (Uint16ToFloat :244-250).
+void Matrix::ReadCompressed(std::istream &is, int format) {
+  struct {
+    float min_value, range;
+    int32 num_rows, num_cols;
+  } h;
+  is.read(reinterpret_cast<char *>(&h), sizeof(h));
+  if (is.fail()) KaldiErr("Failed to read header");
+  if (h.num_cols == 0) {
+    Resize(0, 0);
+    return;
+  }
+  if (h.num_rows < 0 || h.num_cols < 0) KaldiErr("Failed to read matrix from stream: negative size");
+  Resize(h.num_rows, h.num_cols);
+  auto u16 = [&](uint16_t v) { return h.min_value + h.range * 1.52590218966964e-05F * v; };
+  if (format == 1) {
+    std::vector<uint16_t> pc(static_cast<size_t>(4) * h.num_cols);
+    is.read(reinterpret_cast<char *>(pc.data()), static_cast<std::streamsize>(pc.size() * 2));
+    std::vector<unsigned char> col(h.num_rows);
+    for (int32 c = 0; c < h.num_cols; ++c) {
+      const float p0 = u16(pc[4 * c]), p25 = u16(pc[4 * c + 1]), p75 = u16(pc[4 * c + 2]),
+                  p100 = u16(pc[4 * c + 3]);
+      is.read(reinterpret_cast<char *>(col.data()), h.num_rows);
+      for (int32 r = 0; r < h.num_rows; ++r) {
+        const unsigned char v = col[r];
+        float f;
+        if (v <= 64) f = p0 + (p25 - p0) * v * (1 / 64.0);
+        else if (v <= 192) f = p25 + (p75 - p25) * (v - 64) * (1 / 128.0);
+        else f = p75 + (p100 - p75) * (v - 192) * (1 / 63.0);
+        (*this)(r, c) = f;
+      }
+    }
+  } else {
+    std::vector<uint16_t> row(h.num_cols);
+    for (int32 r = 0; r < h.num_rows; ++r) {
+      is.read(reinterpret_cast<char *>(row.data()), static_cast<std::streamsize>(2) * h.num_cols);
+      for (int32 c = 0; c < h.num_cols; ++c) (*this)(r, c) = u16(row[c]);
+    }
+  }
+  if (is.fail()) KaldiErr("Failed to read data.");
+}
+
 void Matrix::Read(std::istream &is, bool binary) {
   if (binary) {
     std::string tok;
     ReadToken(is, binary, &tok);
-    if (tok == "CM")
-      KaldiErr("Failed to read matrix from stream: compressed matrices (CM) are not supported by this build; "
-               "convert with copy-feats --compress=false");
+    if (tok == "CM" || tok == "CM2") {
+      ReadCompressed(is, tok == "CM" ? 1 : 2);
+      return;
+    }
     if (tok != "FM" && tok != "DM")
       KALDI_AMD_ERR("Failed to read matrix from stream: expected token FM or DM, got " << tok);
     int32 rows, cols;

@@ -86,10 +86,11 @@ class Matrix {
   float &operator()(int32 r, int32 c) { return RowData(r)[c]; }
   float operator()(int32 r, int32 c) const { return RowData(r)[c]; }
   void Swap(Matrix *other);
-  void Read(std::istream &is, bool binary);  // "FM", "DM" or text; "CM" is rejected with a message
+  void Read(std::istream &is, bool binary);  // "FM", "DM", "CM" / "CM2" (compressed) or text
   void Write(std::ostream &os, bool binary) const;
 
  private:
+  void ReadCompressed(std::istream &is, int format);
   int32 rows_ = 0, cols_ = 0, stride_ = 0;
   std::vector<float> data_;
 };

@@ -173,6 +173,12 @@ int main(int argc, char *argv[]) {
                 << n.RightContext() << " num-components " << n.NumComponents()
                 << " priors-dim " << am.Priors().Dim() << "\n";
       return 0;
+    } else if (cmd == "compress-feats") {
+      // writes every matrix as a CompressedMatrix ("CM" / "CM2" on disk)
+      SequentialBaseFloatMatrixReader reader(argv[2]);
+      CompressedMatrixWriter writer(argv[3]);
+      for (; !reader.Done(); reader.Next()) writer.Write(reader.Key(), CompressedMatrix(reader.Value()));
+      return 0;
     } else if (cmd == "copy-feats") {
       SequentialBaseFloatMatrixReader reader(argv[2]);
       BaseFloatMatrixWriter writer(argv[3]);

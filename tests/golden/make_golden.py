@@ -14,6 +14,7 @@ Files written (all small):
   gmm_b.mdl  gmm_b_feats.ark  gmm_b_likes.ark  dim 13, one very large pdf (split over waves on the GPU)
   nnet_a.mdl nnet_a_feats.ark nnet_a_post.ark nnet_a_log.ark nnet_a_loglikes.ark nnet_a_post_nopad.ark
   nnet_b.mdl nnet_b_feats.ark nnet_b_post.ark  sigmoid / tanh / relu / mix-up sum-group network
+  cm_feats.ark  cm_feats_expanded.ark          CompressedMatrix archive and its expansion
 """
 import os
 import sys
@@ -111,6 +112,15 @@ def main():
     ]
     pri_b = np.random.default_rng(5).dirichlet(np.ones(20)).astype(np.float32)
     nnet_case("nnet_b", comps_b, pri_b, [("m", rng.standard_normal((33, 10)).astype(np.float32))], full=False)
+    # Compressed feature matrices as the reference writes them: "CM" (per-column percentiles +
+    # bytes) for the 50- and 40-row matrices, "CM2" (16-bit) for the 7-row one; and what the
+    # reference's Matrix<float>::Read makes of them.
+    cm_items = [("c1", synth.make_feats(a, 50, seed=4010)), ("c2", synth.make_feats(a, 7, seed=4011)),
+                ("c3", (rng.standard_normal((40, 13)) * 20).astype(np.float32))]
+    kio.write_ark(path("cm_src.ark"), cm_items)
+    oracle.ref_driver("compress-feats", "ark:" + path("cm_src.ark"), "ark:" + path("cm_feats.ark"))
+    oracle.ref_driver("copy-feats", "ark:" + path("cm_feats.ark"), "ark:" + path("cm_feats_expanded.ark"))
+    os.remove(path("cm_src.ark"))
     total = sum(os.path.getsize(path(f)) for f in os.listdir(HERE) if not f.endswith(".py"))
     print("golden files: %d bytes" % total)
 

@@ -158,3 +158,18 @@ def test_bad_input_is_an_error(tmp_path):
     open(bad, "wb").write(b"\0B<NotAModel> ")
     p = subprocess.run([COPY, "gmm", bad, str(tmp_path / "o")], capture_output=True)
     assert p.returncode != 0 and b"ERROR" in p.stderr
+
+
+def test_compressed_matrix_archive_is_expanded_like_the_reference(tmp_path):
+    """"CM" / "CM2" feature archives (matrix/compressed-matrix.cc) read by the C++ table reader
+    must expand to exactly what the reference's own Matrix<float>::Read gives."""
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    raw = open(os.path.join(golden, "cm_feats.ark"), "rb").read()
+    assert b"CM " in raw and b"CM2 " in raw
+    out = str(tmp_path / "expanded.ark")
+    run("feats", "ark:" + os.path.join(golden, "cm_feats.ark"), "ark:" + out)
+    want = kio.read_ark(os.path.join(golden, "cm_feats_expanded.ark"))
+    got = kio.read_ark(out)
+    assert [k for k, _ in got] == [k for k, _ in want] == ["c1", "c2", "c3"]
+    for (_, a), (_, b) in zip(got, want):
+        np.testing.assert_array_equal(a, b)
