@@ -88,7 +88,10 @@ int amlike_gmm_score(amlike_gmm_t *gmm, const float *feats, int32_t T, int32_t l
 
 /* Device-pointer form: feats/out are device memory, the work is enqueued on
  * `stream` (a hipStream_t, or NULL for the default stream) and NOT waited for.
- * The NaN/Inf flag of the most recent launch is read with amlike_gmm_poll(). */
+ * The NaN/Inf flag of the most recent launch is read with amlike_gmm_poll().
+ * A handle owns one set of device scratch buffers (operand images of the features,
+ * partial sums): launches on one handle must be ordered, i.e. issued on one stream or
+ * serialised by the caller.  For concurrent scoring create one handle per thread. */
 int amlike_gmm_score_dev(amlike_gmm_t *gmm, const float *d_feats, int32_t T, int32_t ld,
                          int32_t feat_dim, float log_sum_exp_prune, float *d_out,
                          int32_t ldo, void *stream);
