@@ -1525,6 +1525,25 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
   int nby = std::max(1, (T + target - 1) / target);
   // Small batches: split the frames further so that at least ~2 blocks per CU exist.
   while (nbx * nby < 2 * cus && (T + nby - 1) / nby > 64) ++nby;
+  // One block per CU runs at a time, so the launch takes ceil(blocks / CUs) rounds of
+  // (frames per block + start-up); pick the split near the target that wastes least of
+  // the last round.  The start-up (loading the operand registers) costs about as much as
+  // 96 frames of scoring.
+  if (!getenv("AMLIKE_GMM_FPB")) {
+    double best_cost = 0.0;
+    int best = nby;
+    for (int cand = std::max(1, nby - nby / 4); cand <= nby + nby / 3 + 1; ++cand) {
+      const int f = ((T + cand - 1) / cand + 31) & ~31;
+      if (f < 64) break;
+      const int nb = nbx * ((T + f - 1) / f);
+      const double cost = (double)((nb + cus - 1) / cus) * (f + 96);
+      if (best_cost == 0.0 || cost < best_cost) {
+        best_cost = cost;
+        best = cand;
+      }
+    }
+    nby = best;
+  }
   const int fpb = ((T + nby - 1) / nby + 31) & ~31;
   nby = (T + fpb - 1) / fpb;
   ScoreArgs ar;

@@ -452,6 +452,68 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The same with 16-byte accesses: thread t holds columns 4 (t + 256 k) .. + 3; needs dim,
+// both row strides and both base pointers to be multiples of 4 floats (the swbd output
+// layer is: 8600).
+template <int R4>
+__global__ void __launch_bounds__(256)
+    nnet_softmax4_kernel(const float *__restrict__ in, int ld_in, int dim, int rows, int post,
+                         const float *__restrict__ log_priors, float scale,
+                         float *__restrict__ out, int ld_out, int zero_pad) {
+  __shared__ float s_red[4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int dim4 = dim >> 2;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float4 *x = reinterpret_cast<const float4 *>(in + (size_t)r * ld_in);
+    float4 v[R4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < R4; ++k) {
+      const int c = t + k * 256;
+      v[k] = c < dim4 ? x[c] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      mx = fmaxf(fmaxf(mx, fmaxf(v[k].x, v[k].y)), fmaxf(v[k].z, v[k].w));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) s_red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    __syncthreads();
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < R4; ++k) {
+      v[k].x = __expf(v[k].x - mx);
+      v[k].y = __expf(v[k].y - mx);
+      v[k].z = __expf(v[k].z - mx);
+      v[k].w = __expf(v[k].w - mx);
+      sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) s_red[w] = sum;
+    __syncthreads();
+    sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    float4 *o = reinterpret_cast<float4 *>(out + (size_t)r * ld_out);
+    const float4 *lp = reinterpret_cast<const float4 *>(log_priors);
+#pragma unroll
+    for (int k = 0; k < R4; ++k) {
+      const int c = t + k * 256;
+      if (c < dim4) {
+        float4 q = make_float4(fmaxf(v[k].x * inv, 1.0e-20f), fmaxf(v[k].y * inv, 1.0e-20f),
+                               fmaxf(v[k].z * inv, 1.0e-20f), fmaxf(v[k].w * inv, 1.0e-20f));
+        if (post & kPostFloorLog) q = make_float4(__logf(q.x), __logf(q.y), __logf(q.z), __logf(q.w));
+        if (post & kPostPrior) {
+          const float4 p = lp[c];
+          q = make_float4((q.x - p.x) * scale, (q.y - p.y) * scale, (q.z - p.z) * scale, (q.w - p.w) * scale);
+        }
+        o[c] = q;
+      } else if (zero_pad && 4 * c < ld_out) {
+        o[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+    }
+  }
+}
+
 // Softmax for rows wider than the register form holds: three passes over the row.
 __global__ void __launch_bounds__(256)
     nnet_softmax_wide_kernel(const float *__restrict__ in, int ld_in, int dim, int rows, int post,
@@ -757,7 +819,16 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       AMLIKE_HIP(hipGetLastError());
     } else if (s.kind == AMLIKE_SOFTMAX) {
       const int blocks = (int)std::min<int64_t>(cur_rows, 16384);
-      if (s.in_dim <= 256 * kSoftmaxRegs)
+      const bool vec4 = (s.in_dim & 3) == 0 && (cur_ld & 3) == 0 && (dst_ld & 3) == 0 &&
+                        ((reinterpret_cast<uintptr_t>(cur) | reinterpret_cast<uintptr_t>(dst) |
+                          reinterpret_cast<uintptr_t>(n->d_log_priors)) & 15) == 0;
+      if (vec4 && s.in_dim <= 256 * 4 * 4)
+        hipLaunchKernelGGL(nnet_softmax4_kernel<4>, dim3(blocks), dim3(256), 0, st, cur, cur_ld, s.in_dim,
+                           (int)cur_rows, spost, n->d_log_priors, prob_scale, dst, dst_ld, zero_pad);
+      else if (vec4 && s.in_dim <= 256 * 4 * 10)
+        hipLaunchKernelGGL(nnet_softmax4_kernel<10>, dim3(blocks), dim3(256), 0, st, cur, cur_ld, s.in_dim,
+                           (int)cur_rows, spost, n->d_log_priors, prob_scale, dst, dst_ld, zero_pad);
+      else if (s.in_dim <= 256 * kSoftmaxRegs)
         hipLaunchKernelGGL(nnet_softmax_kernel, dim3(blocks), dim3(256), 0, st, cur, cur_ld, s.in_dim,
                            (int)cur_rows, spost, n->d_log_priors, prob_scale, dst, dst_ld, zero_pad);
       else
