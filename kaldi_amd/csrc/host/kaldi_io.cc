@@ -409,9 +409,89 @@ static void SplitOffset(const std::string &rx, std::string *path, std::streamoff
   }
 }
 
+// ---- pipes -------------------------------------------------------------------
+class PipeStream::Buf : public std::streambuf {
+ public:
+  Buf(FILE *fp, bool reading) : fp_(fp), buf_(1 << 16) {
+    if (reading) setg(buf_.data(), buf_.data(), buf_.data());
+    else setp(buf_.data(), buf_.data() + buf_.size());
+  }
+
+ protected:
+  int_type underflow() override {
+    if (gptr() < egptr()) return traits_type::to_int_type(*gptr());
+    const size_t n = fread(buf_.data(), 1, buf_.size(), fp_);
+    if (n == 0) return traits_type::eof();
+    setg(buf_.data(), buf_.data(), buf_.data() + n);
+    return traits_type::to_int_type(*gptr());
+  }
+  int_type overflow(int_type ch) override {
+    if (sync() != 0) return traits_type::eof();
+    if (!traits_type::eq_int_type(ch, traits_type::eof())) {
+      *pptr() = traits_type::to_char_type(ch);
+      pbump(1);
+    }
+    return traits_type::not_eof(ch);
+  }
+  int sync() override {
+    if (!pbase()) return 0;
+    const size_t n = static_cast<size_t>(pptr() - pbase());
+    if (n && fwrite(pbase(), 1, n, fp_) != n) return -1;
+    setp(buf_.data(), buf_.data() + buf_.size());
+    return fflush(fp_) == 0 ? 0 : -1;
+  }
+
+ private:
+  FILE *fp_;
+  std::vector<char> buf_;
+};
+
+PipeStream::PipeStream(const std::string &command, bool for_reading) : command_(command) {
+  fp_ = popen(command.c_str(), for_reading ? "r" : "w");
+  if (!fp_) KALDI_AMD_ERR("Failed opening pipe for " << (for_reading ? "reading" : "writing")
+                                                    << ", command is: " << command);
+  buf_.reset(new Buf(fp_, for_reading));
+  if (for_reading) in_.reset(new std::istream(buf_.get()));
+  else out_.reset(new std::ostream(buf_.get()));
+}
+
+PipeStream::~PipeStream() {
+  if (out_) out_->flush();
+  in_.reset();
+  out_.reset();
+  buf_.reset();
+  if (fp_) {
+    const int status = pclose(fp_);
+    if (status) std::cerr << "WARNING (kaldi_amd) Pipe " << command_ << " had nonzero return status " << status << "\n";
+  }
+}
+
+static std::string Trim(const std::string &s) {
+  const size_t b = s.find_first_not_of(" \t\r\n"), e = s.find_last_not_of(" \t\r\n");
+  return b == std::string::npos ? std::string() : s.substr(b, e - b + 1);
+}
+
+bool IsInputPipe(const std::string &rxfilename, std::string *command) {
+  const std::string t = Trim(rxfilename);
+  if (t.size() < 2 || t.back() != '|') return false;
+  *command = Trim(t.substr(0, t.size() - 1));
+  return !command->empty();
+}
+
+bool IsOutputPipe(const std::string &wxfilename, std::string *command) {
+  const std::string t = Trim(wxfilename);
+  if (t.size() < 2 || t.front() != '|') return false;
+  *command = Trim(t.substr(1));
+  return !command->empty();
+}
+
 Input::Input(const std::string &rxfilename, bool *binary) {
+  std::string command;
   if (rxfilename == "-" || rxfilename.empty()) {
     is_ = &std::cin;
+  } else if (IsInputPipe(rxfilename, &command)) {
+    pipe_.reset(new PipeStream(command, true));
+    is_ = &pipe_->In();
   } else {
     std::string path;
     std::streamoff off;
@@ -427,8 +507,12 @@ Input::Input(const std::string &rxfilename, bool *binary) {
 }
 
 Output::Output(const std::string &wxfilename, bool binary, bool write_header) {
+  std::string command;
   if (wxfilename == "-" || wxfilename.empty()) {
     os_ = &std::cout;
+  } else if (IsOutputPipe(wxfilename, &command)) {
+    pipe_.reset(new PipeStream(command, false));
+    os_ = &pipe_->Out();
   } else {
     file_.reset(new std::ofstream(wxfilename, std::ios::out | std::ios::binary));
     if (!file_->is_open()) KALDI_AMD_ERR("Error opening output stream " << wxfilename);
@@ -461,8 +545,12 @@ SequentialMatrixReader::SequentialMatrixReader(const std::string &rspecifier) {
   SplitSpecifier(rspecifier, &opts, &rest);
   if (HasOpt(opts, "scp")) is_scp_ = true;
   else if (!HasOpt(opts, "ark")) KALDI_AMD_ERR("Invalid rspecifier " << rspecifier);
+  std::string command;
   if (rest == "-" || rest.empty()) {
     is_ = &std::cin;
+  } else if (IsInputPipe(rest, &command)) {
+    pipe_.reset(new PipeStream(command, true));
+    is_ = &pipe_->In();
   } else {
     file_.reset(new std::ifstream(rest, std::ios::in | std::ios::binary));
     if (!file_->is_open()) KALDI_AMD_ERR("Error opening table " << rspecifier);
@@ -514,8 +602,13 @@ MatrixWriter::MatrixWriter(const std::string &wspecifier) {
     rest = rest.substr(0, comma);
   }
   ark_name_ = rest;
+  std::string command;
   if (rest == "-" || rest.empty()) {
     os_ = &std::cout;
+  } else if (IsOutputPipe(rest, &command)) {
+    if (!scp_name.empty()) KALDI_AMD_ERR("Invalid wspecifier (an scp cannot point into a pipe) " << wspecifier);
+    pipe_.reset(new PipeStream(command, false));
+    os_ = &pipe_->Out();
   } else {
     file_.reset(new std::ofstream(rest, std::ios::out | std::ios::binary));
     if (!file_->is_open()) KALDI_AMD_ERR("Error opening table for writing " << wspecifier);

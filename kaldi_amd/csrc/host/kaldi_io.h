@@ -11,6 +11,7 @@
 #define KALDI_AMD_CSRC_HOST_KALDI_IO_H_
 
 #include <cstdint>
+#include <cstdio>
 #include <fstream>
 #include <iostream>
 #include <memory>
@@ -96,7 +97,31 @@ class Matrix {
 };
 
 // ---- files -------------------------------------------------------------------
-// rxfilename: a path, "-" (stdin), or "path:offset".  Opens and detects the binary marker.
+// A shell command as a stream, as the reference's piped rxfilenames / wxfilenames
+// ("gunzip -c feats.gz |", "| gzip -c > likes.gz"; util/kaldi-io.cc PipeInputImpl /
+// PipeOutputImpl): popen() behind a std::streambuf.  A non-zero exit status of the command
+// is reported on stderr when the stream is closed, as the reference does.
+class PipeStream {
+ public:
+  PipeStream(const std::string &command, bool for_reading);
+  ~PipeStream();
+  std::istream &In() { return *in_; }
+  std::ostream &Out() { return *out_; }
+
+ private:
+  class Buf;
+  std::string command_;
+  FILE *fp_ = nullptr;
+  std::unique_ptr<Buf> buf_;
+  std::unique_ptr<std::istream> in_;
+  std::unique_ptr<std::ostream> out_;
+};
+// True for "cmd |" (input) / "| cmd" (output); *command gets the command without the bar.
+bool IsInputPipe(const std::string &rxfilename, std::string *command);
+bool IsOutputPipe(const std::string &wxfilename, std::string *command);
+
+// rxfilename: a path, "-" (stdin), "path:offset" or "command |".  Opens and detects the
+// binary marker.
 class Input {
  public:
   Input(const std::string &rxfilename, bool *binary);
@@ -104,6 +129,7 @@ class Input {
 
  private:
   std::unique_ptr<std::ifstream> file_;
+  std::unique_ptr<PipeStream> pipe_;
   std::istream *is_ = nullptr;
 };
 
@@ -115,6 +141,7 @@ class Output {
 
  private:
   std::unique_ptr<std::ofstream> file_;
+  std::unique_ptr<PipeStream> pipe_;
   std::ostream *os_ = nullptr;
 };
 
@@ -133,6 +160,7 @@ class SequentialMatrixReader {
   void ReadOne();
   bool is_scp_ = false;
   std::unique_ptr<std::ifstream> file_;
+  std::unique_ptr<PipeStream> pipe_;
   std::istream *is_ = nullptr;
   bool done_ = false;
   std::string key_;
@@ -150,6 +178,7 @@ class MatrixWriter {
   bool binary_ = true;
   std::string ark_name_;
   std::unique_ptr<std::ofstream> file_, scp_;
+  std::unique_ptr<PipeStream> pipe_;
   std::ostream *os_ = nullptr;
 };
 

@@ -173,3 +173,28 @@ def test_compressed_matrix_archive_is_expanded_like_the_reference(tmp_path):
     assert [k for k, _ in got] == [k for k, _ in want] == ["c1", "c2", "c3"]
     for (_, a), (_, b) in zip(got, want):
         np.testing.assert_array_equal(a, b)
+
+
+def test_piped_rxfilename_and_wxfilename(tmp_path):
+    """"command |" inputs and "| command" outputs, as recipe scripts chain Kaldi tools."""
+    rng = np.random.default_rng(21)
+    items = [("p%d" % i, rng.standard_normal((n, 7)).astype(np.float32)) for i, n in enumerate([4, 300])]
+    src, dst = str(tmp_path / "in.ark"), str(tmp_path / "out.ark.gz")
+    kio.write_ark(src, items)
+    run("feats", "ark:cat %s |" % src, "ark:| gzip -c > %s" % dst)
+    import gzip
+    got = kio.read_ark(gzip.open(dst, "rb").read())
+    assert [k for k, _ in got] == ["p0", "p1"]
+    for (_, a), (_, b) in zip(items, got):
+        np.testing.assert_array_equal(a, b)
+    # a model read through a pipe, and a failing command is an error
+    model = synth.make_gmm(5, 3, 9, seed=2)
+    mdl = str(tmp_path / "m.mdl")
+    write_gmm_mdl(mdl, model, True, with_trans=False)
+    out = str(tmp_path / "m2.mdl")
+    p = subprocess.run([COPY, "gmm", "cat %s |" % mdl, out], capture_output=True)
+    # amlike-copy peeks for a TransitionModel with seekg, which a pipe cannot do; the model
+    # readers themselves are sequential, so reading from a pipe must either work or fail cleanly
+    assert p.returncode in (0, 255)
+    p = subprocess.run([COPY, "feats", "ark:false |", "ark:" + str(tmp_path / "x.ark")], capture_output=True)
+    assert b"nonzero return status" in p.stderr
