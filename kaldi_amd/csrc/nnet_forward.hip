@@ -285,6 +285,158 @@ __global__ void __launch_bounds__(256, 2)
   }
 }
 
+// ---------------------------------------------------------------------------
+// Activations as bf16x3 planes.  A matrix that feeds an affine stage is also written as three
+// bf16 planes, x = p1 + p2 + p3 exactly, each [rows][Kp] with Kp a multiple of 16 and the
+// columns beyond the dimension zero: 8 consecutive k of one row are then one 16-byte MFMA
+// operand fragment, and the GEMM stages its X tile without any conversion work (measured:
+// splitting inside the GEMM's k-loop costs 40 % of its time, the separate pass 3 %).
+struct Planes {
+  unsigned short *p;  // plane q starts at p + q * stride
+  size_t stride;      // elements per plane = rows * Kp
+  int Kp;
+};
+
+__device__ __forceinline__ void store_planes(const Planes &o, size_t idx, float x) {
+  const __bf16 b1 = static_cast<__bf16>(x);
+  const float r1 = x - static_cast<float>(b1);
+  const __bf16 b2 = static_cast<__bf16>(r1);
+  const float r2 = r1 - static_cast<float>(b2);
+  const __bf16 b3 = static_cast<__bf16>(r2);
+  o.p[idx] = __builtin_bit_cast(unsigned short, b1);
+  o.p[o.stride + idx] = __builtin_bit_cast(unsigned short, b2);
+  o.p[2 * o.stride + idx] = __builtin_bit_cast(unsigned short, b3);
+}
+
+// fp32 [rows x ld] (first dim columns) -> planes, zero padded, in k-octet-major order:
+// plane q, octet o (columns 8o .. 8o+7), row r is the 16-byte element q * stride/8 + o * rows + r.
+// With the rows of one octet contiguous, the GEMM's staging loads (32 rows x one octet per
+// half-wave) read 512 contiguous bytes instead of 16 bytes from each of 32 cache lines.
+__global__ void __launch_bounds__(256)
+    nnet_split_planes_kernel(const float *__restrict__ in, int ld, int dim, int rows, Planes out) {
+  const int kp8 = out.Kp >> 3;
+  const size_t n = (size_t)rows * kp8;
+  uint4 *o = reinterpret_cast<uint4 *>(out.p);
+  const size_t pstride = out.stride >> 3;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t oct = i / rows, r = i - oct * rows;
+    const int c0 = (int)oct * 8;
+    const float *x = in + r * ld + c0;
+    float4 lo, hi;
+    if (c0 + 8 <= dim) {
+      lo = *reinterpret_cast<const float4 *>(x);
+      hi = *reinterpret_cast<const float4 *>(x + 4);
+    } else {
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = c0 + j < dim ? x[j] : 0.0f;
+      lo = make_float4(t[0], t[1], t[2], t[3]);
+      hi = make_float4(t[4], t[5], t[6], t[7]);
+    }
+    uint4 s0, s1, s2;
+    split_bf16x3_8(lo, hi, s0, s1, s2);
+    o[i] = s0;
+    o[pstride + i] = s1;
+    o[2 * pstride + i] = s2;
+  }
+}
+
+// The bf16x3 GEMM with both operands given as k-octet-major planes (X: [3][Kp/8][M], W:
+// [3][Kp/8][N] 16-byte elements): same tiling and LDS image as nnet_gemm_bias_bf16x3_kernel
+// (block tile 128 x 128, three blocks per CU), but both operand tiles are plain, fully
+// coalesced 16-byte copies global -> registers -> LDS.  (A 128 x 256 block tile with
+// 64 x 128 wave tiles was measured 15 % slower: it drops to two blocks per CU.)
+__global__ void __launch_bounds__(256, 2)
+    nnet_gemm_bias_planes_kernel(const uint4 *__restrict__ Xp, size_t xplane,
+                                 const uint4 *__restrict__ Wp, int Kp,
+                                 const float *__restrict__ bias, float *__restrict__ Y, int ldy,
+                                 int M, int N) {
+  __shared__ __attribute__((aligned(16))) uint4 s_x[2][3][4][2][32];
+  __shared__ __attribute__((aligned(16))) uint4 s_w[2][3][4][2][32];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = w >> 1, wc = w & 1, li = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int srow = w * 32 + li;
+  const int kp8 = Kp >> 3, nk = Kp >> 4;
+  // element of (row, octet o): o * rows + row
+  const size_t xrow = (size_t)h * M + min(m0 + srow, M - 1);
+  const size_t wrow = (size_t)h * N + min(n0 + srow, N - 1);
+  const size_t wplane = (size_t)N * kp8;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  uint4 rx0 = Xp[xrow], rx1 = Xp[xplane + xrow], rx2 = Xp[2 * xplane + xrow];
+  uint4 rw0 = Wp[wrow], rw1 = Wp[wplane + wrow], rw2 = Wp[2 * wplane + wrow];
+  s_x[0][0][w][h][li] = rx0;
+  s_x[0][1][w][h][li] = rx1;
+  s_x[0][2][w][h][li] = rx2;
+  s_w[0][0][w][h][li] = rw0;
+  s_w[0][1][w][h][li] = rw1;
+  s_w[0][2][w][h][li] = rw2;
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) {
+      const size_t ox = xrow + (size_t)(ks + 1) * 2 * M, ow = wrow + (size_t)(ks + 1) * 2 * N;
+      rx0 = Xp[ox];
+      rx1 = Xp[xplane + ox];
+      rx2 = Xp[2 * xplane + ox];
+      rw0 = Wp[ow];
+      rw1 = Wp[wplane + ow];
+      rw2 = Wp[2 * wplane + ow];
+    }
+    bf16x8_t fa[2][3], fb[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        fa[mt][q] = __builtin_bit_cast(bf16x8_t, s_x[cur][q][wr * 2 + mt][h][li]);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        fb[nt][q] = __builtin_bit_cast(bf16x8_t, s_w[cur][q][wc * 2 + nt][h][li]);
+#pragma unroll
+    for (int which = 0; which < 6; ++which) {
+      const int pa = which == 0 ? 2 : (which == 1 || which == 3) ? 1 : 0;
+      const int pb = (which == 0 || which == 3 || which == 5) ? 0 : (which == 1 || which == 4) ? 1 : 2;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][pa], fb[nt][pb], acc[mt][nt], 0, 0, 0);
+    }
+    if (ks + 1 < nk) {
+      s_x[cur ^ 1][0][w][h][li] = rx0;
+      s_x[cur ^ 1][1][w][h][li] = rx1;
+      s_x[cur ^ 1][2][w][h][li] = rx2;
+      s_w[cur ^ 1][0][w][h][li] = rw0;
+      s_w[cur ^ 1][1][w][h][li] = rw1;
+      s_w[cur ^ 1][2][w][h][li] = rw2;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n0 + wc * 64 + nt * 32 + li;
+    if (n >= N) continue;
+    const float bv = bias[n];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < M) Y[(size_t)m * ldy + n] = acc[mt][nt][r] + bv;
+      }
+  }
+}
+
 // Zeroes columns [dim, ld) of a [rows x ld] buffer (the k-padding the GEMM reads).
 __global__ void nnet_zero_pad_kernel(float *buf, int rows, int ld, int dim) {
   const int padw = ld - dim;
@@ -605,6 +757,7 @@ struct Stage {
   int normalize_after = 0;  // pnorm fused with the Normalize that follows
   float *d_w = nullptr;     // [out_dim][Kp]
   uint4 *d_wp = nullptr;    // the same split into bf16 planes: [3][out_dim][Kp] bf16
+  uint4 *d_wpo = nullptr;   // the planes in k-octet-major order: [3][Kp/8][out_dim] x 16 bytes
   float *d_bias = nullptr;
   int Kp = 0;
   int32_t *d_begins = nullptr;  // sumgroup prefix [out_dim + 1]
@@ -619,9 +772,10 @@ struct amlike_nnet {
   int input_dim = 0, output_dim = 0, left = 0, right = 0;
   int num_priors = 0;
   bool gemm_f32 = false;  // AMLIKE_NNET_GEMM=f32: the exact-fp32 MFMA GEMM (A/B check of the bf16x3 one)
+  bool gemm_inline_split = false;  // AMLIKE_NNET_GEMM=inline: bf16x3 GEMM that splits X in its k-loop
   float *d_log_priors = nullptr;
   hipStream_t stream = nullptr;
-  DeviceBuffer ws_a, ws_b, ws_in, ws_out, ws_utts;
+  DeviceBuffer ws_a, ws_b, ws_in, ws_out, ws_utts, ws_planes;
   std::vector<UttMap> h_utts;
   std::mutex mu;
 };
@@ -632,6 +786,7 @@ static void FreeNnet(amlike_nnet *n) {
   for (Stage &s : n->stages) {
     (void)hipFree(s.d_w);
     (void)hipFree(s.d_wp);
+    (void)hipFree(s.d_wpo);
     (void)hipFree(s.d_bias);
     (void)hipFree(s.d_begins);
   }
@@ -641,6 +796,7 @@ static void FreeNnet(amlike_nnet *n) {
   n->ws_in.Free();
   n->ws_out.Free();
   n->ws_utts.Free();
+  n->ws_planes.Free();
   if (n->stream) (void)hipStreamDestroy(n->stream);
   delete n;
 }
@@ -793,9 +949,23 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       if (n->gemm_f32)
         hipLaunchKernelGGL(nnet_gemm_bias_kernel, grid, dim3(256), 0, st, cur, cur_ld, s.d_w, s.Kp,
                            s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
-      else
+      else if (n->gemm_inline_split)
         hipLaunchKernelGGL(nnet_gemm_bias_bf16x3_kernel, grid, dim3(256), 0, st, cur, cur_ld, s.d_wp,
                            s.Kp, s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
+      else {
+        // the input as bf16x3 planes (one cheap pass), then the conversion-free GEMM
+        const size_t pstride = (size_t)cur_rows * s.Kp;
+        rc = n->ws_planes.Reserve(3 * pstride * sizeof(unsigned short));
+        if (rc != AMLIKE_OK) return rc;
+        Planes xp{static_cast<unsigned short *>(n->ws_planes.ptr), pstride, s.Kp};
+        const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
+        hipLaunchKernelGGL(nnet_split_planes_kernel, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                           s.in_dim, (int)cur_rows, xp);
+        AMLIKE_HIP(hipGetLastError());
+        hipLaunchKernelGGL(nnet_gemm_bias_planes_kernel, grid, dim3(256), 0, st,
+                           static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo, s.Kp,
+                           s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
+      }
       AMLIKE_HIP(hipGetLastError());
       if (!last && dst_ld != s.out_dim) {
         hipLaunchKernelGGL(nnet_zero_pad_kernel, dim3(256), dim3(256), 0, st, dst, (int)cur_rows,
@@ -882,7 +1052,10 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
     if (rc != AMLIKE_OK) return rc;
   }
   amlike_nnet *n = new amlike_nnet;
-  if (const char *e = getenv("AMLIKE_NNET_GEMM")) n->gemm_f32 = strcmp(e, "f32") == 0;
+  if (const char *e = getenv("AMLIKE_NNET_GEMM")) {
+    n->gemm_f32 = strcmp(e, "f32") == 0;
+    n->gemm_inline_split = strcmp(e, "inline") == 0;
+  }
   n->input_dim = comps[0].input_dim;
   int dim = comps[0].input_dim;
   int rc = AMLIKE_OK;
@@ -929,7 +1102,18 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
           SplitBf16x3(w[idx], parts);
           for (int q = 0; q < 3; ++q) wp[q * w.size() + idx] = parts[q];
         }
+        std::vector<uint16_t> wpo(3 * w.size());
+        {
+          const size_t kp8 = s.Kp / 8, N = c.output_dim;
+          for (int q = 0; q < 3; ++q)
+            for (size_t r = 0; r < N; ++r)
+              for (size_t o = 0; o < kp8; ++o)
+                memcpy(&wpo[q * w.size() + (o * N + r) * 8], &wp[q * w.size() + r * s.Kp + o * 8], 16);
+        }
         hipError_t e = hipMalloc(&s.d_w, w.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&s.d_wpo, wpo.size() * sizeof(uint16_t));
+        if (e == hipSuccess)
+          e = hipMemcpy(s.d_wpo, wpo.data(), wpo.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(s.d_w, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc(&s.d_wp, wp.size() * sizeof(uint16_t));
         if (e == hipSuccess)
@@ -990,6 +1174,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
     if (rc != AMLIKE_OK) {
       (void)hipFree(s.d_w);
       (void)hipFree(s.d_wp);
+      (void)hipFree(s.d_wpo);
       (void)hipFree(s.d_bias);
       (void)hipFree(s.d_begins);
       break;
