@@ -313,7 +313,8 @@ __device__ __forceinline__ void store_planes(const Planes &o, size_t idx, float 
 // With the rows of one octet contiguous, the GEMM's staging loads (32 rows x one octet per
 // half-wave) read 512 contiguous bytes instead of 16 bytes from each of 32 cache lines.
 __global__ void __launch_bounds__(256)
-    nnet_split_planes_kernel(const float *__restrict__ in, int ld, int dim, int rows, Planes out) {
+    nnet_split_planes_kernel(const float *__restrict__ in, int ld, int dim, int rows, Planes out,
+                             int one_col) {
   const int kp8 = out.Kp >> 3;
   const size_t n = (size_t)rows * kp8;
   uint4 *o = reinterpret_cast<uint4 *>(out.p);
@@ -327,9 +328,11 @@ __global__ void __launch_bounds__(256)
       lo = *reinterpret_cast<const float4 *>(x);
       hi = *reinterpret_cast<const float4 *>(x + 4);
     } else {
+      // the tail octets: zero padding, and 1.0 in column one_col (the bias column of the
+      // fused affine + p-norm GEMM; one_col < 0: none)
       float t[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = c0 + j < dim ? x[j] : 0.0f;
+      for (int j = 0; j < 8; ++j) t[j] = c0 + j < dim ? x[j] : (c0 + j == one_col ? 1.0f : 0.0f);
       lo = make_float4(t[0], t[1], t[2], t[3]);
       hi = make_float4(t[4], t[5], t[6], t[7]);
     }
@@ -434,6 +437,113 @@ __global__ void __launch_bounds__(256, 2)
         const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < M) Y[(size_t)m * ldy + n] = acc[mt][nt][r] + bv;
       }
+  }
+}
+
+// Affine + p-norm (p = 2) in one kernel: out[t][g] = sqrt(sum_{j < GS} (W x_t + b)[g GS + j]^2).
+// The operand roles are swapped against the kernels above: the units (rows of W) are the
+// MFMA's A operand, so they land on the accumulator's register axis, and the frames are its
+// columns (one per lane).  The host permutes the rows of W (BuildPnormWeights) so that the
+// 80 accumulator values a half-lane holds over five 32-unit tiles are 80 / GS complete
+// p-norm groups: the group sums are then plain per-lane arithmetic, and the kernel writes
+// [T x groups] instead of [T x units] -- a tenth of the bytes at GS = 10, and the separate
+// p-norm pass over [T x units] disappears.  The bias rides in W as column K against a
+// constant 1.0 column of X (nnet_split_planes_kernel, one_col).
+// Block: 160 units x 128 frames, 4 waves, wave w = frames [32 w, 32 w + 32) x all 160 units.
+template <int GS>
+__global__ void __launch_bounds__(256, 2)
+    nnet_gemm_pnorm_kernel(const uint4 *__restrict__ Xp, size_t xplane, const uint4 *__restrict__ Wp,
+                           int Kp, float *__restrict__ Y, int ldy, int M, int Npad, int G) {
+  static_assert(80 % GS == 0, "a half-lane holds 80 units");
+  __shared__ __attribute__((aligned(16))) uint4 s_x[2][3][4][64];
+  __shared__ __attribute__((aligned(16))) uint4 s_w[2][3][5][64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int u0 = blockIdx.x * 160, m0 = blockIdx.y * 128;
+  const int kp8 = Kp >> 3, nk = Kp >> 4;
+  const size_t wplane = (size_t)Npad * kp8;
+  // staging: wave w copies X row block w and W row blocks w and w + 4 (w + 4 exists for w = 0)
+  const size_t xrow = (size_t)h * M + min(m0 + w * 32 + li, M - 1);
+  const size_t wrow0 = (size_t)h * Npad + u0 + w * 32 + li;
+  const size_t wrow1 = (size_t)h * Npad + u0 + 128 + li;  // row block 4, staged by wave 0
+  const bool second = w == 0;
+
+  f32x16 acc[5];
+#pragma unroll
+  for (int a = 0; a < 5; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+
+  uint4 rx0, rx1, rx2, ra0, ra1, ra2, rb0, rb1, rb2;
+  rb0 = rb1 = rb2 = make_uint4(0, 0, 0, 0);
+  auto fetch = [&](int ks) {
+    const size_t ox = xrow + (size_t)ks * 2 * M, oa = wrow0 + (size_t)ks * 2 * Npad;
+    rx0 = Xp[ox];
+    rx1 = Xp[xplane + ox];
+    rx2 = Xp[2 * xplane + ox];
+    ra0 = Wp[oa];
+    ra1 = Wp[wplane + oa];
+    ra2 = Wp[2 * wplane + oa];
+    if (second) {
+      const size_t ob = wrow1 + (size_t)ks * 2 * Npad;
+      rb0 = Wp[ob];
+      rb1 = Wp[wplane + ob];
+      rb2 = Wp[2 * wplane + ob];
+    }
+  };
+  auto commit = [&](int buf) {
+    s_x[buf][0][w][lane] = rx0;
+    s_x[buf][1][w][lane] = rx1;
+    s_x[buf][2][w][lane] = rx2;
+    s_w[buf][0][w][lane] = ra0;
+    s_w[buf][1][w][lane] = ra1;
+    s_w[buf][2][w][lane] = ra2;
+    if (second) {
+      s_w[buf][0][4][lane] = rb0;
+      s_w[buf][1][4][lane] = rb1;
+      s_w[buf][2][4][lane] = rb2;
+    }
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) fetch(ks + 1);
+    bf16x8_t fw[5][3], fx[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fx[q] = __builtin_bit_cast(bf16x8_t, s_x[cur][q][w][lane]);
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fw[a][q] = __builtin_bit_cast(bf16x8_t, s_w[cur][q][a][lane]);
+#pragma unroll
+    for (int which = 0; which < 6; ++which) {
+      const int pa = which == 0 ? 2 : (which == 1 || which == 3) ? 1 : 0;
+      const int pb = (which == 0 || which == 3 || which == 5) ? 0 : (which == 1 || which == 4) ? 1 : 2;
+#pragma unroll
+      for (int a = 0; a < 5; ++a)
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[a][pa], fx[pb], acc[a], 0, 0, 0);
+    }
+    if (ks + 1 < nk) commit(cur ^ 1);
+    __syncthreads();
+  }
+  // Epilogue: this lane is frame m0 + 32 w + li; its 80 values (tile a, register r) are slots
+  // a * 16 + r = GS-sized groups number (80 / GS) * (2 * blockIdx.x + h) + slot / GS.
+  const int m = m0 + w * 32 + li;
+  if (m >= M) return;
+  float *o = Y + (size_t)m * ldy;
+  const int g0 = (80 / GS) * (2 * blockIdx.x + h);
+#pragma unroll
+  for (int gl = 0; gl < 80 / GS; ++gl) {
+    float ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < GS; ++j) {
+      const int slot = gl * GS + j;
+      const float v = acc[slot >> 4][slot & 15];
+      ss = fmaf(v, v, ss);
+    }
+    if (g0 + gl < G) o[g0 + gl] = sqrtf(ss);
   }
 }
 
@@ -758,6 +868,10 @@ struct Stage {
   float *d_w = nullptr;     // [out_dim][Kp]
   uint4 *d_wp = nullptr;    // the same split into bf16 planes: [3][out_dim][Kp] bf16
   uint4 *d_wpo = nullptr;   // the planes in k-octet-major order: [3][Kp/8][out_dim] x 16 bytes
+  // affine followed by a p = 2 p-norm whose group size divides 80: the fused kernel's image
+  uint4 *d_wpn = nullptr;   // rows permuted and padded to Npad, bias as column in_dim: [3][Kpn/8][Npad]
+  int fuse_gs = 0, Kpn = 0, Npad = 0;
+  std::vector<float> h_w, h_b;  // host copies kept until the next component is known
   float *d_bias = nullptr;
   int Kp = 0;
   int32_t *d_begins = nullptr;  // sumgroup prefix [out_dim + 1]
@@ -787,6 +901,7 @@ static void FreeNnet(amlike_nnet *n) {
     (void)hipFree(s.d_w);
     (void)hipFree(s.d_wp);
     (void)hipFree(s.d_wpo);
+    (void)hipFree(s.d_wpn);
     (void)hipFree(s.d_bias);
     (void)hipFree(s.d_begins);
   }
@@ -804,6 +919,33 @@ static void FreeNnet(amlike_nnet *n) {
 // Runs the pipeline over a batch of utterances laid out back to back in d_feats.
 // utt_rows[u] = input frames of utterance u.  Output rows are laid out back to back too
 // (out_rows[u] = rows - left - right when !pad_input).  Returns total output rows.
+// The operand image of nnet_gemm_pnorm_kernel: rows of W permuted so that, per block of
+// 160 units, unit 80 hh + s (hh = 0, 1; s = 0 .. 79) sits in MFMA tile s / 16 at row
+// (r & 3) + 8 (r >> 2) + 4 hh with r = s % 16 -- the row that accumulator register r of
+// half-wave hh holds; the bias as column K; rows padded to a multiple of 160, columns to a
+// multiple of 16; split into bf16x3 planes in k-octet-major order.
+static std::vector<uint16_t> BuildPnormWeights(const std::vector<float> &w, int ldw,
+                                               const std::vector<float> &bias, int N, int K,
+                                               int *Kpn, int *Npad) {
+  *Kpn = RoundUp(K + 1, 16);
+  *Npad = RoundUp(N, 160);
+  const size_t kp8 = *Kpn / 8, np = *Npad;
+  std::vector<uint16_t> out(3 * np * *Kpn, 0);
+  for (int u = 0; u < N; ++u) {
+    const int wt = u / 160, hh = (u % 160) / 80, sl = u % 80;
+    const int ti = sl / 16, r = sl % 16, rho = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    const size_t row = (size_t)wt * 160 + ti * 32 + rho;
+    for (int k = 0; k <= K; ++k) {
+      uint16_t parts[3];
+      SplitBf16x3(k < K ? w[(size_t)u * ldw + k] : bias[u], parts);
+      for (int q = 0; q < 3; ++q)
+        out[q * np * *Kpn + (((size_t)(k / 8) * np + row) * 8) + (k % 8)] = parts[q];
+    }
+  }
+  (void)kp8;
+  return out;
+}
+
 static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *utt_rows,
                    int num_utts, int pad_input, int mode, float prob_scale, float *d_out, int ldo,
                    hipStream_t st, int64_t *total_out_rows) {
@@ -940,6 +1082,62 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       }
       out_rows = gather_rows[gi++];
       padded = true;
+    } else if (s.kind == AMLIKE_AFFINE && s.fuse_gs && si + 1 < ns) {
+      // affine + p-norm (+ normalize) : planes of the input with a 1.0 column for the bias,
+      // the fused GEMM writing [rows x groups], then the row normalisation.
+      const Stage &pn = n->stages[si + 1];
+      const bool pn_last = (si + 2 == ns);
+      const size_t pstride = (size_t)cur_rows * s.Kpn;
+      rc = n->ws_planes.Reserve(3 * pstride * sizeof(unsigned short));
+      if (rc != AMLIKE_OK) return rc;
+      Planes xp{static_cast<unsigned short *>(n->ws_planes.ptr), pstride, s.Kpn};
+      const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
+      hipLaunchKernelGGL(nnet_split_planes_kernel, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                         s.in_dim, (int)cur_rows, xp, s.in_dim);
+      AMLIKE_HIP(hipGetLastError());
+      const int G = pn.out_dim;
+      // without a Normalize the p-norm output is this pair's result; with one it goes to the
+      // other scratch buffer first
+      const bool norm = pn.normalize_after != 0;
+      float *pdst = norm ? bufs[which] : (pn_last ? d_out : bufs[which]);
+      const int pld = norm ? RoundUp(G, 16) : (pn_last ? ldo : RoundUp(G, 16));
+      dim3 fgrid(s.Npad / 160, (unsigned)((cur_rows + 127) / 128));
+      const uint4 *xpl = static_cast<const uint4 *>(n->ws_planes.ptr);
+      if (s.fuse_gs == 10)
+        hipLaunchKernelGGL(nnet_gemm_pnorm_kernel<10>, fgrid, dim3(256), 0, st, xpl, pstride / 8, s.d_wpn,
+                           s.Kpn, pdst, pld, (int)cur_rows, s.Npad, G);
+      else if (s.fuse_gs == 5)
+        hipLaunchKernelGGL(nnet_gemm_pnorm_kernel<5>, fgrid, dim3(256), 0, st, xpl, pstride / 8, s.d_wpn,
+                           s.Kpn, pdst, pld, (int)cur_rows, s.Npad, G);
+      else
+        hipLaunchKernelGGL(nnet_gemm_pnorm_kernel<8>, fgrid, dim3(256), 0, st, xpl, pstride / 8, s.d_wpn,
+                           s.Kpn, pdst, pld, (int)cur_rows, s.Npad, G);
+      AMLIKE_HIP(hipGetLastError());
+      float *fin = pdst;
+      int fin_ld = pld;
+      if (norm) {
+        fin = pn_last ? d_out : bufs[which ^ 1];
+        fin_ld = pn_last ? ldo : RoundUp(G, 16);
+        const int blocks = (int)std::min<int64_t>((cur_rows + 3) / 4, 8192);
+        hipLaunchKernelGGL(nnet_normalize_kernel, dim3(blocks), dim3(256), 0, st, pdst, pld, G,
+                           (int)cur_rows, fin, fin_ld, pn_last ? 0 : 1);
+        AMLIKE_HIP(hipGetLastError());
+        which ^= 1;  // the result sits in the other buffer
+      } else if (!pn_last && pld != G) {
+        hipLaunchKernelGGL(nnet_zero_pad_kernel, dim3(256), dim3(256), 0, st, pdst, (int)cur_rows, pld, G);
+        AMLIKE_HIP(hipGetLastError());
+      }
+      if (pn_last && post) {
+        const int blocks = (int)std::min<int64_t>(cur_rows, 16384);
+        hipLaunchKernelGGL(nnet_elementwise_kernel, dim3(blocks), dim3(256), 0, st, d_out, ldo, G,
+                           (int)cur_rows, 0, post, n->d_log_priors, prob_scale, d_out, ldo, 0);
+        AMLIKE_HIP(hipGetLastError());
+      }
+      cur = fin;
+      cur_ld = fin_ld;
+      which ^= 1;
+      ++si;  // the p-norm stage is done
+      continue;
     } else if (s.kind == AMLIKE_AFFINE) {
       if (cur_ld < s.Kp || (cur_ld & 3) || (reinterpret_cast<uintptr_t>(cur) & 15)) {
         SetError("amlike_nnet_compute: internal layout error before an affine stage");
@@ -960,7 +1158,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         Planes xp{static_cast<unsigned short *>(n->ws_planes.ptr), pstride, s.Kp};
         const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
         hipLaunchKernelGGL(nnet_split_planes_kernel, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
-                           s.in_dim, (int)cur_rows, xp);
+                           s.in_dim, (int)cur_rows, xp, -1);
         AMLIKE_HIP(hipGetLastError());
         hipLaunchKernelGGL(nnet_gemm_bias_planes_kernel, grid, dim3(256), 0, st,
                            static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo, s.Kp,
@@ -1096,6 +1294,8 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
         std::vector<float> w((size_t)c.output_dim * s.Kp, 0.0f);
         for (int r = 0; r < c.output_dim; ++r)
           memcpy(&w[(size_t)r * s.Kp], c.linear + (size_t)r * c.input_dim, c.input_dim * sizeof(float));
+        s.h_w = w;
+        s.h_b.assign(c.bias, c.bias + c.output_dim);
         std::vector<uint16_t> wp(3 * w.size());
         for (size_t idx = 0; idx < w.size(); ++idx) {
           uint16_t parts[3];
@@ -1133,6 +1333,24 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
             (size_t)4 * c.input_dim * sizeof(float) > 60 * 1024) {
           SetError("amlike_nnet_create: bad PnormComponent %d", i);
           rc = AMLIKE_EINVAL;
+        } else if (!n->stages.empty() && n->stages.back().kind == AMLIKE_AFFINE && c.p == 2.0f &&
+                   !n->gemm_f32 && !n->gemm_inline_split && !getenv("AMLIKE_NNET_NOFUSE")) {
+          // affine + p-norm in one kernel when the group size is one the kernel is built for
+          Stage &a = n->stages.back();
+          const int gs = c.input_dim / c.output_dim;
+          if ((gs == 10 || gs == 5 || gs == 8) && a.out_dim == c.input_dim && !a.h_w.empty()) {
+            std::vector<uint16_t> img = BuildPnormWeights(a.h_w, a.Kp, a.h_b, a.out_dim, a.in_dim,
+                                                          &a.Kpn, &a.Npad);
+            hipError_t e = hipMalloc(&a.d_wpn, img.size() * sizeof(uint16_t));
+            if (e == hipSuccess)
+              e = hipMemcpy(a.d_wpn, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+              SetError("amlike_nnet_create: %s", hipGetErrorString(e));
+              rc = e == hipErrorOutOfMemory ? AMLIKE_EOOM : AMLIKE_EHIP;
+            } else {
+              a.fuse_gs = gs;
+            }
+          }
         }
         break;
       case AMLIKE_SUMGROUP: {
@@ -1189,6 +1407,10 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
     dim = c.output_dim;
   }
   n->output_dim = dim;
+  for (Stage &st : n->stages) {
+    std::vector<float>().swap(st.h_w);
+    std::vector<float>().swap(st.h_b);
+  }
   if (rc == AMLIKE_OK && priors && num_priors > 0) {
     std::vector<float> lp(num_priors);
     for (int i = 0; i < num_priors; ++i) lp[i] = logf(priors[i]);
