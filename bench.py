@@ -163,9 +163,9 @@ def main():
     traffic = None
     if args.config == "swbd_tri4" and "gmm_score_diff_kernel<5,2,8,2,f16x2>" in am.kernel_info() \
             and T == 35554:
-        traffic = {"bytes": 2.0 * 686038e3 + 1257140e3, "fetch_bytes": 2.0 * 686038e3,
-                   "write_bytes": 1257140e3, "algorithmic_bytes": 4.0 * T * P + 4.0 * T * D,
-                   "source": "profiles/r1_d_gmm_diff_pmc_summary.txt"}
+        traffic = {"bytes": 2.0 * 616323e3 + 1265390e3, "fetch_bytes": 2.0 * 616323e3,
+                   "write_bytes": 1265390e3, "algorithmic_bytes": 4.0 * T * P + 4.0 * T * D,
+                   "source": "profiles/r1_e_gmm_diff_pmc_summary.txt"}
 
     if rank == 0:
         value = tot_frames * args.steps / elapsed

@@ -111,3 +111,24 @@ def test_exact_fp32_gemm_gives_the_same_answers(amlike_device, monkeypatch):
     assert np.abs(outs["bf16x3"] - outs["f32"]).max() <= 2e-4
     for o in outs.values():
         assert np.abs(o - want).max() <= 1e-3
+
+
+@pytest.mark.parametrize("hidden,pnorm_out", [(400, 40), (320, 40), (250, 50), (210, 30)])
+def test_fused_affine_pnorm_matches_unfused_and_oracle(amlike_device, hidden, pnorm_out, monkeypatch):
+    """Group sizes 10, 8 and 5 run the fused affine + p-norm kernel, 7 the separate kernels;
+    all must agree with the oracle, and fused with unfused to fp32 rounding."""
+    comps, priors = synth.make_pnorm_nnet(input_dim=24, left=2, right=2, hidden=hidden,
+                                          pnorm_out=pnorm_out, num_hidden=2, num_pdfs=333, seed=71)
+    feats = np.random.default_rng(72).standard_normal((203, 24)).astype(np.float32) * 2.0
+    want = oracle.nnet_compute(comps, priors, feats, pad_input=True, mode=2, prob_scale=1.0)
+    outs = {}
+    for nofuse in ("", "1"):
+        if nofuse:
+            monkeypatch.setenv("AMLIKE_NNET_NOFUSE", "1")
+        else:
+            monkeypatch.delenv("AMLIKE_NNET_NOFUSE", raising=False)
+        net = nnet.AmNnet(comps, priors)
+        outs[nofuse] = net.Compute(feats, pad_input=True, mode=nnet.LOGLIKES, prob_scale=1.0)
+        net.close()
+        assert np.abs(outs[nofuse] - want).max() <= 1e-3
+    assert np.abs(outs[""] - outs["1"]).max() <= 2e-4
