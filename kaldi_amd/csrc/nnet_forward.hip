@@ -285,6 +285,44 @@ __global__ void __launch_bounds__(256, 2)
   }
 }
 
+// fp16x2: 8 floats -> two words sets of packed fp16 pairs, x = p1 + p2 to 22 bits.  Used where
+// the values are known to sit inside the fp16 range (activations behind a NormalizeComponent,
+// |x| <= sqrt(dim); weights checked at load): 3 partial products instead of 6.
+__device__ __forceinline__ void split_f16x2_2(float a, float b, unsigned &o1, unsigned &o2) {
+  const _Float16 a1 = static_cast<_Float16>(a), b1 = static_cast<_Float16>(b);
+  const _Float16 a2 = static_cast<_Float16>(a - static_cast<float>(a1));
+  const _Float16 b2 = static_cast<_Float16>(b - static_cast<float>(b1));
+  o1 = __builtin_bit_cast(unsigned short, a1) | (unsigned)__builtin_bit_cast(unsigned short, b1) << 16;
+  o2 = __builtin_bit_cast(unsigned short, a2) | (unsigned)__builtin_bit_cast(unsigned short, b2) << 16;
+}
+__device__ __forceinline__ void split_f16x2_8(const float4 &lo, const float4 &hi, uint4 &o1, uint4 &o2) {
+  split_f16x2_2(lo.x, lo.y, o1.x, o2.x);
+  split_f16x2_2(lo.z, lo.w, o1.y, o2.y);
+  split_f16x2_2(hi.x, hi.y, o1.z, o2.z);
+  split_f16x2_2(hi.z, hi.w, o1.w, o2.w);
+}
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// One MFMA of a split product: PREC = 1 fp16 operands, 0 bf16 (both arrive as raw 16-bit lanes).
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma16(bf16x8_t a, bf16x8_t b, f32x16 c) {
+  if (PREC)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// Partial product `which` of a split product, small terms first: parts (pa, pb) of the two
+// operands.  bf16x3: 6 products; fp16x2: 3.
+template <int PREC>
+__device__ __forceinline__ void product_parts(int which, int &pa, int &pb) {
+  if (PREC) {
+    pa = which == 0 ? 1 : 0;
+    pb = which == 1 ? 1 : 0;
+  } else {
+    pa = which == 0 ? 2 : (which == 1 || which == 3) ? 1 : 0;
+    pb = (which == 0 || which == 3 || which == 5) ? 0 : (which == 1 || which == 4) ? 1 : 2;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Activations as bf16x3 planes.  A matrix that feeds an affine stage is also written as three
 // bf16 planes, x = p1 + p2 + p3 exactly, each [rows][Kp] with Kp a multiple of 16 and the
@@ -312,6 +350,7 @@ __device__ __forceinline__ void store_planes(const Planes &o, size_t idx, float 
 // plane q, octet o (columns 8o .. 8o+7), row r is the 16-byte element q * stride/8 + o * rows + r.
 // With the rows of one octet contiguous, the GEMM's staging loads (32 rows x one octet per
 // half-wave) read 512 contiguous bytes instead of 16 bytes from each of 32 cache lines.
+template <int PREC>
 __global__ void __launch_bounds__(256)
     nnet_split_planes_kernel(const float *__restrict__ in, int ld, int dim, int rows, Planes out,
                              int one_col) {
@@ -336,11 +375,18 @@ __global__ void __launch_bounds__(256)
       lo = make_float4(t[0], t[1], t[2], t[3]);
       hi = make_float4(t[4], t[5], t[6], t[7]);
     }
-    uint4 s0, s1, s2;
-    split_bf16x3_8(lo, hi, s0, s1, s2);
-    o[i] = s0;
-    o[pstride + i] = s1;
-    o[2 * pstride + i] = s2;
+    if (PREC) {
+      uint4 s0, s1;
+      split_f16x2_8(lo, hi, s0, s1);
+      o[i] = s0;
+      o[pstride + i] = s1;
+    } else {
+      uint4 s0, s1, s2;
+      split_bf16x3_8(lo, hi, s0, s1, s2);
+      o[i] = s0;
+      o[pstride + i] = s1;
+      o[2 * pstride + i] = s2;
+    }
   }
 }
 
@@ -349,13 +395,15 @@ __global__ void __launch_bounds__(256)
 // (block tile 128 x 128, three blocks per CU), but both operand tiles are plain, fully
 // coalesced 16-byte copies global -> registers -> LDS.  (A 128 x 256 block tile with
 // 64 x 128 wave tiles was measured 15 % slower: it drops to two blocks per CU.)
+template <int PREC>
 __global__ void __launch_bounds__(256, 2)
     nnet_gemm_bias_planes_kernel(const uint4 *__restrict__ Xp, size_t xplane,
                                  const uint4 *__restrict__ Wp, int Kp,
                                  const float *__restrict__ bias, float *__restrict__ Y, int ldy,
                                  int M, int N) {
-  __shared__ __attribute__((aligned(16))) uint4 s_x[2][3][4][2][32];
-  __shared__ __attribute__((aligned(16))) uint4 s_w[2][3][4][2][32];
+  constexpr int NPL = PREC ? 2 : 3, NPROD = PREC ? 3 : 6;
+  __shared__ __attribute__((aligned(16))) uint4 s_x[2][NPL][4][2][32];
+  __shared__ __attribute__((aligned(16))) uint4 s_w[2][NPL][4][2][32];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wr = w >> 1, wc = w & 1, li = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
@@ -374,14 +422,20 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  uint4 rx0 = Xp[xrow], rx1 = Xp[xplane + xrow], rx2 = Xp[2 * xplane + xrow];
-  uint4 rw0 = Wp[wrow], rw1 = Wp[wplane + wrow], rw2 = Wp[2 * wplane + wrow];
+  uint4 rx0 = Xp[xrow], rx1 = Xp[xplane + xrow], rx2 = rx0;
+  uint4 rw0 = Wp[wrow], rw1 = Wp[wplane + wrow], rw2 = rw0;
+  if (NPL == 3) {
+    rx2 = Xp[2 * xplane + xrow];
+    rw2 = Wp[2 * wplane + wrow];
+  }
   s_x[0][0][w][h][li] = rx0;
   s_x[0][1][w][h][li] = rx1;
-  s_x[0][2][w][h][li] = rx2;
   s_w[0][0][w][h][li] = rw0;
   s_w[0][1][w][h][li] = rw1;
-  s_w[0][2][w][h][li] = rw2;
+  if (NPL == 3) {
+    s_x[0][NPL - 1][w][h][li] = rx2;
+    s_w[0][NPL - 1][w][h][li] = rw2;
+  }
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
     const int cur = ks & 1;
@@ -389,39 +443,42 @@ __global__ void __launch_bounds__(256, 2)
       const size_t ox = xrow + (size_t)(ks + 1) * 2 * M, ow = wrow + (size_t)(ks + 1) * 2 * N;
       rx0 = Xp[ox];
       rx1 = Xp[xplane + ox];
-      rx2 = Xp[2 * xplane + ox];
       rw0 = Wp[ow];
       rw1 = Wp[wplane + ow];
-      rw2 = Wp[2 * wplane + ow];
+      if (NPL == 3) {
+        rx2 = Xp[2 * xplane + ox];
+        rw2 = Wp[2 * wplane + ow];
+      }
     }
-    bf16x8_t fa[2][3], fb[2][3];
+    bf16x8_t fa[2][NPL], fb[2][NPL];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < NPL; ++q)
         fa[mt][q] = __builtin_bit_cast(bf16x8_t, s_x[cur][q][wr * 2 + mt][h][li]);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < NPL; ++q)
         fb[nt][q] = __builtin_bit_cast(bf16x8_t, s_w[cur][q][wc * 2 + nt][h][li]);
 #pragma unroll
-    for (int which = 0; which < 6; ++which) {
-      const int pa = which == 0 ? 2 : (which == 1 || which == 3) ? 1 : 0;
-      const int pb = (which == 0 || which == 3 || which == 5) ? 0 : (which == 1 || which == 4) ? 1 : 2;
+    for (int which = 0; which < NPROD; ++which) {
+      int pa, pb;
+      product_parts<PREC>(which, pa, pb);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][pa], fb[nt][pb], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16<PREC>(fa[mt][pa], fb[nt][pb], acc[mt][nt]);
     }
     if (ks + 1 < nk) {
       s_x[cur ^ 1][0][w][h][li] = rx0;
       s_x[cur ^ 1][1][w][h][li] = rx1;
-      s_x[cur ^ 1][2][w][h][li] = rx2;
       s_w[cur ^ 1][0][w][h][li] = rw0;
       s_w[cur ^ 1][1][w][h][li] = rw1;
-      s_w[cur ^ 1][2][w][h][li] = rw2;
+      if (NPL == 3) {
+        s_x[cur ^ 1][NPL - 1][w][h][li] = rx2;
+        s_w[cur ^ 1][NPL - 1][w][h][li] = rw2;
+      }
     }
     __syncthreads();
   }
@@ -450,13 +507,14 @@ __global__ void __launch_bounds__(256, 2)
 // p-norm pass over [T x units] disappears.  The bias rides in W as column K against a
 // constant 1.0 column of X (nnet_split_planes_kernel, one_col).
 // Block: 160 units x 128 frames, 4 waves, wave w = frames [32 w, 32 w + 32) x all 160 units.
-template <int GS>
+template <int GS, int PREC>
 __global__ void __launch_bounds__(256, 2)
     nnet_gemm_pnorm_kernel(const uint4 *__restrict__ Xp, size_t xplane, const uint4 *__restrict__ Wp,
                            int Kp, float *__restrict__ Y, int ldy, int M, int Npad, int G) {
   static_assert(80 % GS == 0, "a half-lane holds 80 units");
-  __shared__ __attribute__((aligned(16))) uint4 s_x[2][3][4][64];
-  __shared__ __attribute__((aligned(16))) uint4 s_w[2][3][5][64];
+  constexpr int NPL = PREC ? 2 : 3, NPROD = PREC ? 3 : 6;
+  __shared__ __attribute__((aligned(16))) uint4 s_x[2][NPL][4][64];
+  __shared__ __attribute__((aligned(16))) uint4 s_w[2][NPL][5][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int u0 = blockIdx.x * 160, m0 = blockIdx.y * 128;
@@ -475,33 +533,37 @@ __global__ void __launch_bounds__(256, 2)
     for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
 
   uint4 rx0, rx1, rx2, ra0, ra1, ra2, rb0, rb1, rb2;
-  rb0 = rb1 = rb2 = make_uint4(0, 0, 0, 0);
+  rx2 = ra2 = rb0 = rb1 = rb2 = make_uint4(0, 0, 0, 0);
   auto fetch = [&](int ks) {
     const size_t ox = xrow + (size_t)ks * 2 * M, oa = wrow0 + (size_t)ks * 2 * Npad;
     rx0 = Xp[ox];
     rx1 = Xp[xplane + ox];
-    rx2 = Xp[2 * xplane + ox];
     ra0 = Wp[oa];
     ra1 = Wp[wplane + oa];
-    ra2 = Wp[2 * wplane + oa];
+    if (NPL == 3) {
+      rx2 = Xp[2 * xplane + ox];
+      ra2 = Wp[2 * wplane + oa];
+    }
     if (second) {
       const size_t ob = wrow1 + (size_t)ks * 2 * Npad;
       rb0 = Wp[ob];
       rb1 = Wp[wplane + ob];
-      rb2 = Wp[2 * wplane + ob];
+      if (NPL == 3) rb2 = Wp[2 * wplane + ob];
     }
   };
   auto commit = [&](int buf) {
     s_x[buf][0][w][lane] = rx0;
     s_x[buf][1][w][lane] = rx1;
-    s_x[buf][2][w][lane] = rx2;
     s_w[buf][0][w][lane] = ra0;
     s_w[buf][1][w][lane] = ra1;
-    s_w[buf][2][w][lane] = ra2;
+    if (NPL == 3) {
+      s_x[buf][NPL - 1][w][lane] = rx2;
+      s_w[buf][NPL - 1][w][lane] = ra2;
+    }
     if (second) {
       s_w[buf][0][4][lane] = rb0;
       s_w[buf][1][4][lane] = rb1;
-      s_w[buf][2][4][lane] = rb2;
+      if (NPL == 3) s_w[buf][NPL - 1][4][lane] = rb2;
     }
   };
   fetch(0);
@@ -510,20 +572,19 @@ __global__ void __launch_bounds__(256, 2)
   for (int ks = 0; ks < nk; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < nk) fetch(ks + 1);
-    bf16x8_t fw[5][3], fx[3];
+    bf16x8_t fw[5][NPL], fx[NPL];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) fx[q] = __builtin_bit_cast(bf16x8_t, s_x[cur][q][w][lane]);
+    for (int q = 0; q < NPL; ++q) fx[q] = __builtin_bit_cast(bf16x8_t, s_x[cur][q][w][lane]);
 #pragma unroll
     for (int a = 0; a < 5; ++a)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) fw[a][q] = __builtin_bit_cast(bf16x8_t, s_w[cur][q][a][lane]);
+      for (int q = 0; q < NPL; ++q) fw[a][q] = __builtin_bit_cast(bf16x8_t, s_w[cur][q][a][lane]);
 #pragma unroll
-    for (int which = 0; which < 6; ++which) {
-      const int pa = which == 0 ? 2 : (which == 1 || which == 3) ? 1 : 0;
-      const int pb = (which == 0 || which == 3 || which == 5) ? 0 : (which == 1 || which == 4) ? 1 : 2;
+    for (int which = 0; which < NPROD; ++which) {
+      int pa, pb;
+      product_parts<PREC>(which, pa, pb);
 #pragma unroll
-      for (int a = 0; a < 5; ++a)
-        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[a][pa], fx[pb], acc[a], 0, 0, 0);
+      for (int a = 0; a < 5; ++a) acc[a] = mfma16<PREC>(fw[a][pa], fx[pb], acc[a]);
     }
     if (ks + 1 < nk) commit(cur ^ 1);
     __syncthreads();
@@ -871,6 +932,7 @@ struct Stage {
   // affine followed by a p = 2 p-norm whose group size divides 80: the fused kernel's image
   uint4 *d_wpn = nullptr;   // rows permuted and padded to Npad, bias as column in_dim: [3][Kpn/8][Npad]
   int fuse_gs = 0, Kpn = 0, Npad = 0;
+  int f16 = 0;  // operands as fp16x2 (input behind a NormalizeComponent, weights inside the fp16 range)
   std::vector<float> h_w, h_b;  // host copies kept until the next component is known
   float *d_bias = nullptr;
   int Kp = 0;
@@ -924,21 +986,50 @@ static void FreeNnet(amlike_nnet *n) {
 // (r & 3) + 8 (r >> 2) + 4 hh with r = s % 16 -- the row that accumulator register r of
 // half-wave hh holds; the bias as column K; rows padded to a multiple of 160, columns to a
 // multiple of 16; split into bf16x3 planes in k-octet-major order.
+// x as NPL 16-bit parts: bf16x3 (exact) or fp16x2 (22 bits).
+static inline void SplitParts(float x, int f16, uint16_t parts[3]) {
+  if (!f16) {
+    SplitBf16x3(x, parts);
+    return;
+  }
+  const _Float16 h1 = static_cast<_Float16>(x);
+  const _Float16 h2 = static_cast<_Float16>(x - static_cast<float>(h1));
+  memcpy(&parts[0], &h1, 2);
+  memcpy(&parts[1], &h2, 2);
+  parts[2] = 0;
+}
+
+// Plain operand image of W for nnet_gemm_bias_planes_kernel: [NPL][Kp/8][N] x 16 bytes.
+static std::vector<uint16_t> BuildPlaneWeights(const std::vector<float> &w, int Kp, int N, int f16) {
+  const int npl = f16 ? 2 : 3;
+  const size_t kp8 = Kp / 8, plane = (size_t)N * Kp;
+  std::vector<uint16_t> out(npl * plane, 0);
+  for (size_t r = 0; r < (size_t)N; ++r)
+    for (int k = 0; k < Kp; ++k) {
+      uint16_t parts[3];
+      SplitParts(w[r * Kp + k], f16, parts);
+      for (int q = 0; q < npl; ++q) out[q * plane + (((size_t)(k / 8) * N + r) * 8) + (k % 8)] = parts[q];
+    }
+  (void)kp8;
+  return out;
+}
+
 static std::vector<uint16_t> BuildPnormWeights(const std::vector<float> &w, int ldw,
                                                const std::vector<float> &bias, int N, int K,
-                                               int *Kpn, int *Npad) {
+                                               int f16, int *Kpn, int *Npad) {
   *Kpn = RoundUp(K + 1, 16);
   *Npad = RoundUp(N, 160);
+  const int npl = f16 ? 2 : 3;
   const size_t kp8 = *Kpn / 8, np = *Npad;
-  std::vector<uint16_t> out(3 * np * *Kpn, 0);
+  std::vector<uint16_t> out(npl * np * *Kpn, 0);
   for (int u = 0; u < N; ++u) {
     const int wt = u / 160, hh = (u % 160) / 80, sl = u % 80;
     const int ti = sl / 16, r = sl % 16, rho = (r & 3) + 8 * (r >> 2) + 4 * hh;
     const size_t row = (size_t)wt * 160 + ti * 32 + rho;
     for (int k = 0; k <= K; ++k) {
       uint16_t parts[3];
-      SplitBf16x3(k < K ? w[(size_t)u * ldw + k] : bias[u], parts);
-      for (int q = 0; q < 3; ++q)
+      SplitParts(k < K ? w[(size_t)u * ldw + k] : bias[u], f16, parts);
+      for (int q = 0; q < npl; ++q)
         out[q * np * *Kpn + (((size_t)(k / 8) * np + row) * 8) + (k % 8)] = parts[q];
     }
   }
@@ -1092,8 +1183,12 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       if (rc != AMLIKE_OK) return rc;
       Planes xp{static_cast<unsigned short *>(n->ws_planes.ptr), pstride, s.Kpn};
       const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
-      hipLaunchKernelGGL(nnet_split_planes_kernel, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
-                         s.in_dim, (int)cur_rows, xp, s.in_dim);
+      if (s.f16)
+        hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                           s.in_dim, (int)cur_rows, xp, s.in_dim);
+      else
+        hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                           s.in_dim, (int)cur_rows, xp, s.in_dim);
       AMLIKE_HIP(hipGetLastError());
       const int G = pn.out_dim;
       // without a Normalize the p-norm output is this pair's result; with one it goes to the
@@ -1103,15 +1198,16 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       const int pld = norm ? RoundUp(G, 16) : (pn_last ? ldo : RoundUp(G, 16));
       dim3 fgrid(s.Npad / 160, (unsigned)((cur_rows + 127) / 128));
       const uint4 *xpl = static_cast<const uint4 *>(n->ws_planes.ptr);
-      if (s.fuse_gs == 10)
-        hipLaunchKernelGGL(nnet_gemm_pnorm_kernel<10>, fgrid, dim3(256), 0, st, xpl, pstride / 8, s.d_wpn,
-                           s.Kpn, pdst, pld, (int)cur_rows, s.Npad, G);
-      else if (s.fuse_gs == 5)
-        hipLaunchKernelGGL(nnet_gemm_pnorm_kernel<5>, fgrid, dim3(256), 0, st, xpl, pstride / 8, s.d_wpn,
-                           s.Kpn, pdst, pld, (int)cur_rows, s.Npad, G);
-      else
-        hipLaunchKernelGGL(nnet_gemm_pnorm_kernel<8>, fgrid, dim3(256), 0, st, xpl, pstride / 8, s.d_wpn,
-                           s.Kpn, pdst, pld, (int)cur_rows, s.Npad, G);
+#define AMLIKE_PNORM_LAUNCH(GS, PREC)                                                              \
+  hipLaunchKernelGGL((nnet_gemm_pnorm_kernel<GS, PREC>), fgrid, dim3(256), 0, st, xpl, pstride / 8,   \
+                     s.d_wpn, s.Kpn, pdst, pld, (int)cur_rows, s.Npad, G)
+      if (s.fuse_gs == 10 && s.f16) AMLIKE_PNORM_LAUNCH(10, 1);
+      else if (s.fuse_gs == 10) AMLIKE_PNORM_LAUNCH(10, 0);
+      else if (s.fuse_gs == 5 && s.f16) AMLIKE_PNORM_LAUNCH(5, 1);
+      else if (s.fuse_gs == 5) AMLIKE_PNORM_LAUNCH(5, 0);
+      else if (s.f16) AMLIKE_PNORM_LAUNCH(8, 1);
+      else AMLIKE_PNORM_LAUNCH(8, 0);
+#undef AMLIKE_PNORM_LAUNCH
       AMLIKE_HIP(hipGetLastError());
       float *fin = pdst;
       int fin_ld = pld;
@@ -1157,12 +1253,21 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         if (rc != AMLIKE_OK) return rc;
         Planes xp{static_cast<unsigned short *>(n->ws_planes.ptr), pstride, s.Kp};
         const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
-        hipLaunchKernelGGL(nnet_split_planes_kernel, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
-                           s.in_dim, (int)cur_rows, xp, -1);
-        AMLIKE_HIP(hipGetLastError());
-        hipLaunchKernelGGL(nnet_gemm_bias_planes_kernel, grid, dim3(256), 0, st,
-                           static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo, s.Kp,
-                           s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
+        if (s.f16) {
+          hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                             s.in_dim, (int)cur_rows, xp, -1);
+          AMLIKE_HIP(hipGetLastError());
+          hipLaunchKernelGGL(nnet_gemm_bias_planes_kernel<1>, grid, dim3(256), 0, st,
+                             static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo, s.Kp,
+                             s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
+        } else {
+          hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                             s.in_dim, (int)cur_rows, xp, -1);
+          AMLIKE_HIP(hipGetLastError());
+          hipLaunchKernelGGL(nnet_gemm_bias_planes_kernel<0>, grid, dim3(256), 0, st,
+                             static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo, s.Kp,
+                             s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
+        }
       }
       AMLIKE_HIP(hipGetLastError());
       if (!last && dst_ld != s.out_dim) {
@@ -1302,14 +1407,16 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
           SplitBf16x3(w[idx], parts);
           for (int q = 0; q < 3; ++q) wp[q * w.size() + idx] = parts[q];
         }
-        std::vector<uint16_t> wpo(3 * w.size());
+        // fp16x2 operands where the input is the output of a NormalizeComponent (every value
+        // within sqrt(dim)) and the parameters are well inside the fp16 range
         {
-          const size_t kp8 = s.Kp / 8, N = c.output_dim;
-          for (int q = 0; q < 3; ++q)
-            for (size_t r = 0; r < N; ++r)
-              for (size_t o = 0; o < kp8; ++o)
-                memcpy(&wpo[q * w.size() + (o * N + r) * 8], &wp[q * w.size() + r * s.Kp + o * 8], 16);
+          float wmax = 0.0f;
+          for (float v : w) wmax = std::max(wmax, std::fabs(v));
+          for (int r = 0; r < c.output_dim; ++r) wmax = std::max(wmax, std::fabs(c.bias[r]));
+          s.f16 = i > 0 && comps[i - 1].kind == AMLIKE_NORMALIZE && std::isfinite(wmax) &&
+                  wmax <= 1024.0f && !getenv("AMLIKE_NNET_NOF16");
         }
+        std::vector<uint16_t> wpo = BuildPlaneWeights(w, s.Kp, c.output_dim, s.f16);
         hipError_t e = hipMalloc(&s.d_w, w.size() * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(&s.d_wpo, wpo.size() * sizeof(uint16_t));
         if (e == hipSuccess)
@@ -1340,7 +1447,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
           const int gs = c.input_dim / c.output_dim;
           if ((gs == 10 || gs == 5 || gs == 8) && a.out_dim == c.input_dim && !a.h_w.empty()) {
             std::vector<uint16_t> img = BuildPnormWeights(a.h_w, a.Kp, a.h_b, a.out_dim, a.in_dim,
-                                                          &a.Kpn, &a.Npad);
+                                                          a.f16, &a.Kpn, &a.Npad);
             hipError_t e = hipMalloc(&a.d_wpn, img.size() * sizeof(uint16_t));
             if (e == hipSuccess)
               e = hipMemcpy(a.d_wpn, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
