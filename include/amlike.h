@@ -112,6 +112,16 @@ int amlike_gmm_gauss_loglikes_dev(amlike_gmm_t *gmm, int32_t pdf_begin, int32_t 
                                   const float *d_feats, int32_t T, int32_t ld,
                                   int32_t feat_dim, float *d_out, int32_t ldo, void *stream);
 
+/* Replaces DiagGmm::GaussianSelection(Matrix) (gmm/diag-gmm.cc:801-871) for Gaussian mixture
+ * `pdf` of the packed model (a single UBM is the case num_pdfs == 1, pdf == 0): for every frame
+ * the num_gselect best Gaussians by per-Gaussian log-likelihood, best first, ties towards
+ * the larger index; out_idx is [T x num_gselect] int32 (indices within the mixture, -1 where
+ * num_gselect exceeds its size); *tot_loglike (may be NULL) = sum over frames of the log-sum
+ * of the selected scores, the function's return value in the reference.  Host pointers. */
+int amlike_gmm_gselect(amlike_gmm_t *gmm, int32_t pdf, const float *feats, int32_t T, int32_t ld,
+                       int32_t feat_dim, int32_t num_gselect, int32_t *out_idx,
+                       double *tot_loglike);
+
 /* Name and grid of the kernels the last score launch used (for profiling output). */
 const char *amlike_gmm_kernel_info(const amlike_gmm_t *gmm);
 

@@ -48,6 +48,7 @@ def _declare(lib):
         "amlike_gmm_poll": (ctypes.c_int, [c_void_p, c_void_p]),
         "amlike_gmm_gauss_loglikes": (ctypes.c_int, [c_void_p, c_int32, c_int32, fp, c_int32, c_int32, c_int32, fp, c_int32]),
         "amlike_gmm_gauss_loglikes_dev": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+        "amlike_gmm_gselect": (ctypes.c_int, [c_void_p, c_int32, fp, c_int32, c_int32, c_int32, c_int32, ip, POINTER(ctypes.c_double)]),
         "amlike_gmm_kernel_info": (c_char_p, [c_void_p]),
         "amlike_gmm_time_score_dev": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, POINTER(c_float)]),
         "amlike_nnet_create": (ctypes.c_int, [POINTER(Component), c_int32, fp, c_int32, POINTER(c_void_p)]),

@@ -1062,6 +1062,75 @@ __global__ void __launch_bounds__(256)
   if (!(fabsf(v) <= kMaxAbsLogLike)) atomicOr(flag, 1);
 }
 
+
+// DiagGmm::GaussianSelection (/root/reference/src/gmm/diag-gmm.cc:801-871) on precomputed
+// per-Gaussian scores: one wave per frame; the frame's scores sit in registers (kGselKeep per
+// lane, i.e. up to 64 * kGselKeep Gaussians), and num_gselect rounds of a wave-wide argmax pick
+// the best remaining one.  Ties go to the larger index, as std::greater<pair<float,int>> does.
+// out_idx: [T x num_gselect] (-1 where num_gselect > num_mix); out_ll[t] = log-sum of the
+// selected scores, accumulated in pick order like the reference's LogAdd chain.
+constexpr int kGselKeep = 64;
+__global__ void __launch_bounds__(256)
+    gmm_gselect_kernel(const float *__restrict__ scores, int lds, int num_mix, int T,
+                       int num_gselect, int32_t *__restrict__ out_idx, float *__restrict__ out_ll) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const float *f = scores + (size_t)t * lds;
+  float v[kGselKeep];
+#pragma unroll
+  for (int k = 0; k < kGselKeep; ++k) {
+    const int g = lane + 64 * k;
+    v[k] = g < num_mix ? f[g] : -INFINITY;
+  }
+  float tot = -INFINITY;
+  for (int j = 0; j < num_gselect; ++j) {
+    // lane-local best (value, index); index -1 = nothing left
+    float bv = -INFINITY;
+    int bi = -1;
+#pragma unroll
+    for (int k = 0; k < kGselKeep; ++k) {
+      const int g = lane + 64 * k;
+      // v[k] > -inf is false for retired entries (NaN) and for disabled Gaussians (-inf)
+      const bool take = g < num_mix && v[k] > -INFINITY && (bi < 0 || v[k] > bv || (v[k] == bv && g > bi));
+      // a score of -inf (a disabled Gaussian) can still be selected once nothing else is left
+      bv = take ? v[k] : bv;
+      bi = take ? g : bi;
+    }
+    if (bi < 0) {  // only -inf scores (or nothing) left in this lane: offer the largest unused index
+#pragma unroll
+      for (int k = 0; k < kGselKeep; ++k) {
+        const int g = lane + 64 * k;
+        if (g < num_mix && v[k] == -INFINITY && g > bi) bi = g;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o);
+      const bool take = oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi));
+      bv = take ? ov : bv;
+      bi = take ? oi : bi;
+    }
+    if (lane == 0) out_idx[(size_t)t * num_gselect + j] = bi;
+    if (bi < 0) continue;
+    // retire the winner: NaN marks "used" (a NaN never compares greater or equal)
+#pragma unroll
+    for (int k = 0; k < kGselKeep; ++k)
+      if (lane + 64 * k == bi) v[k] = __builtin_nanf("");
+    // LogAdd(tot, bv)
+    float x = tot, diff;
+    if (x < bv) {
+      diff = x - bv;
+      x = bv;
+    } else {
+      diff = bv - x;
+    }
+    tot = diff >= -15.9423847198486328125f ? x + log1pf(expf(diff)) : x;
+  }
+  if (lane == 0) out_ll[t] = tot;
+}
+
 // ---------------------------------------------------------------------------
 // Host side: the packed model.
 
@@ -1945,6 +2014,63 @@ int amlike_gmm_gauss_loglikes(amlike_gmm_t *g, int32_t pdf_begin, int32_t pdf_en
                                 hipMemcpyDeviceToHost, g->stream));
     AMLIKE_HIP(hipStreamSynchronize(g->stream));
   }
+  return AMLIKE_OK;
+}
+
+int amlike_gmm_gselect(amlike_gmm_t *g, int32_t pdf, const float *feats, int32_t T, int32_t ld,
+                       int32_t feat_dim, int32_t num_gselect, int32_t *out_idx, double *tot_loglike) {
+  if (!g || !feats || !out_idx || pdf < 0 || pdf >= g->num_pdfs || num_gselect <= 0 || T <= 0 ||
+      ld < feat_dim) {
+    SetError("amlike_gmm_gselect: invalid argument");
+    return AMLIKE_EINVAL;
+  }
+  if (feat_dim != g->dim) {
+    SetError("DiagGmm::GaussianSelection, dimension mismatch %d vs. %d", feat_dim, g->dim);
+    return AMLIKE_EDIM;
+  }
+  const int M = g->pdf_offsets[pdf + 1] - g->pdf_offsets[pdf];
+  if (M > 64 * kGselKeep) {
+    SetError("amlike_gmm_gselect: %d Gaussians in one pdf (limit %d)", M, 64 * kGselKeep);
+    return AMLIKE_EINVAL;
+  }
+  std::lock_guard<std::mutex> lock(g->mu);
+  // frame chunks that keep the [chunk x M] score matrix near 256 MiB
+  const int max_t = std::max(64, (int)std::min<size_t>(1u << 20, ((size_t)1 << 26) / (size_t)M));
+  const bool feats_1d = (size_t)ld <= (size_t)2 * feat_dim + 8;
+  const int dld = feats_1d ? ld : feat_dim;
+  std::vector<float> ll;
+  double total = 0.0;
+  for (int t0 = 0; t0 < T; t0 += max_t) {
+    const int tn = std::min(max_t, T - t0);
+    int rc = g->ws_feats.Reserve((size_t)tn * dld * sizeof(float));
+    if (rc == AMLIKE_OK) rc = g->ws_gauss.Reserve((size_t)tn * M * sizeof(float));
+    if (rc == AMLIKE_OK)
+      rc = g->ws_out.Reserve((size_t)tn * num_gselect * sizeof(int32_t) + (size_t)tn * sizeof(float));
+    if (rc != AMLIKE_OK) return rc;
+    float *df = static_cast<float *>(g->ws_feats.ptr);
+    float *dscore = static_cast<float *>(g->ws_gauss.ptr);
+    int32_t *didx = static_cast<int32_t *>(g->ws_out.ptr);
+    float *dll = reinterpret_cast<float *>(didx + (size_t)tn * num_gselect);
+    if (feats_1d)
+      AMLIKE_HIP(hipMemcpyAsync(df, feats + (size_t)t0 * ld, ((size_t)(tn - 1) * ld + feat_dim) * sizeof(float),
+                                hipMemcpyHostToDevice, g->stream));
+    else
+      AMLIKE_HIP(hipMemcpy2DAsync(df, (size_t)feat_dim * sizeof(float), feats + (size_t)t0 * ld,
+                                  (size_t)ld * sizeof(float), (size_t)feat_dim * sizeof(float), tn,
+                                  hipMemcpyHostToDevice, g->stream));
+    rc = amlike_gmm_gauss_loglikes_dev(g, pdf, pdf + 1, df, tn, dld, feat_dim, dscore, M, g->stream);
+    if (rc != AMLIKE_OK) return rc;
+    hipLaunchKernelGGL(gmm_gselect_kernel, dim3((tn + 3) / 4), dim3(256), 0, g->stream, dscore, M, M, tn,
+                       num_gselect, didx, dll);
+    AMLIKE_HIP(hipGetLastError());
+    ll.resize(tn);
+    AMLIKE_HIP(hipMemcpyAsync(out_idx + (size_t)t0 * num_gselect, didx,
+                              (size_t)tn * num_gselect * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+    AMLIKE_HIP(hipMemcpyAsync(ll.data(), dll, (size_t)tn * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    AMLIKE_HIP(hipStreamSynchronize(g->stream));
+    for (int t = 0; t < tn; ++t) total += ll[t];
+  }
+  if (tot_loglike) *tot_loglike = total;
   return AMLIKE_OK;
 }
 

@@ -268,6 +268,23 @@ void DiagGmm::LogLikelihoods(const Matrix &data, Matrix *loglikes) const {
                                         data.NumCols(), loglikes->Data(), loglikes->Stride()));
 }
 
+BaseFloat DiagGmm::GaussianSelection(const Matrix &data, int32 num_gselect,
+                                     std::vector<std::vector<int32>> *output) const {
+  if (data.NumRows() == 0) KaldiErr("DiagGmm::GaussianSelection: empty data");
+  if (num_gselect <= 0) KaldiErr("DiagGmm::GaussianSelection: num_gselect must be positive");
+  std::vector<int32> idx(static_cast<size_t>(data.NumRows()) * num_gselect);
+  double tot = 0.0;
+  CheckAmlike(amlike_gmm_gselect(Engine(), 0, data.Data(), data.NumRows(), data.Stride(), data.NumCols(),
+                                 num_gselect, idx.data(), &tot));
+  output->assign(data.NumRows(), std::vector<int32>());
+  for (int32 t = 0; t < data.NumRows(); ++t)
+    for (int32 j = 0; j < num_gselect; ++j) {
+      const int32 g = idx[static_cast<size_t>(t) * num_gselect + j];
+      if (g >= 0) (*output)[t].push_back(g);
+    }
+  return static_cast<BaseFloat>(tot);
+}
+
 // ---- AmDiagGmm ---------------------------------------------------------------------
 void AmDiagGmm::Read(std::istream &is, bool binary) {  // gmm/am-diag-gmm.cc:147-161
   int32 num_pdfs, dim;

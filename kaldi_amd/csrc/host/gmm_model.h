@@ -70,6 +70,10 @@ class DiagGmm {
   // gmm/diag-gmm.cc:528-543 / :546-562: per-Gaussian log-likelihoods.
   void LogLikelihoods(const Vector &data, Vector *loglikes) const;
   void LogLikelihoods(const Matrix &data, Matrix *loglikes) const;
+  // gmm/diag-gmm.cc:801-871: per frame the num_gselect best Gaussians, best first; returns
+  // the sum over frames of the log-sum of the selected scores.
+  BaseFloat GaussianSelection(const Matrix &data, int32 num_gselect,
+                              std::vector<std::vector<int32>> *output) const;
 
  private:
   amlike_gmm_t *Engine() const;

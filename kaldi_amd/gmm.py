@@ -124,3 +124,14 @@ class AmDiagGmm:
         _lib.check(_lib.lib().amlike_gmm_gauss_loglikes(self._h, pdf_begin, pdf_end, _fp(feats),
                                                         T, D, D, _fp(out), M))
         return out
+
+    def GaussianSelection(self, feats, num_gselect, pdf=0):
+        """DiagGmm::GaussianSelection (gmm/diag-gmm.cc:801-871) for mixture `pdf`.
+        Returns (indices [T x num_gselect] int32, best first; total log-likelihood)."""
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        T, D = feats.shape
+        idx = np.empty((T, int(num_gselect)), dtype=np.int32)
+        tot = ctypes.c_double(0.0)
+        _lib.check(_lib.lib().amlike_gmm_gselect(self._h, int(pdf), _fp(feats), T, D, D, int(num_gselect),
+                                                 _ip(idx), ctypes.byref(tot)))
+        return idx, tot.value

@@ -109,6 +109,18 @@ def diag_gmm_loglikes_mat(gconsts, miv, iv, feats):
     return out
 
 
+def gselect(scores, num_gselect):
+    """DiagGmm::GaussianSelection on precomputed per-Gaussian scores [T x M].
+    Returns (indices [T x num_gselect] int32, total log-likelihood)."""
+    L = load()
+    scores = np.ascontiguousarray(scores, np.float32)
+    T, M = scores.shape
+    idx = np.empty((T, num_gselect), np.int32)
+    L.oracle_gselect.restype = ctypes.c_double
+    tot = L.oracle_gselect(_fp(scores), T, M, M, int(num_gselect), _ip(idx))
+    return idx, float(tot)
+
+
 # ------------------------------------------------------------------- nnet2
 class NnetLayer(ctypes.Structure):
     _fields_ = [("kind", c_int32), ("input_dim", c_int32), ("output_dim", c_int32),

@@ -16,6 +16,8 @@
  */
 #include <float.h>
 #include <math.h>
+#include <string.h>
+#include <stdlib.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <time.h>
@@ -131,6 +133,39 @@ void oracle_diag_gmm_loglikes_mat(const float *gconsts, const float *means_invva
     oracle_diag_gmm_loglikes_vec(gconsts, means_invvars, inv_vars, num_mix, dim, x, scratch,
                                  out + (size_t)t * ldo);
   }
+}
+
+/* gmm/diag-gmm.cc:801-871  DiagGmm::GaussianSelection(Matrix): per frame the num_gselect
+ * best Gaussians (by per-Gaussian log-likelihood, ties towards the larger index, as
+ * std::greater<pair<float,int>> orders them), best first, and the sum over frames of the
+ * log-sum of the selected scores (LogAdd in float per frame, double over frames).
+ * scores: [T x num_mix] from oracle_diag_gmm_loglikes_mat.  out_idx: [T x num_gselect],
+ * -1 where num_gselect > num_mix. */
+double oracle_gselect(const float *scores, int T, int num_mix, int lds, int num_gselect,
+                      int *out_idx) {
+  double ans = 0.0;
+  char *used = (char *)malloc((size_t)num_mix);
+  for (int t = 0; t < T; t++) {
+    const float *f = scores + (size_t)t * lds;
+    memset(used, 0, (size_t)num_mix);
+    float tot = -INFINITY;
+    for (int j = 0; j < num_gselect; j++) {
+      int best = -1;
+      for (int g = 0; g < num_mix; g++)
+        if (!used[g] && (best < 0 || f[g] > f[best] || (f[g] == f[best] && g > best))) best = g;
+      out_idx[(size_t)t * num_gselect + j] = best;
+      if (best < 0) continue;
+      used[best] = 1;
+      /* LogAdd(tot, f[best]), base/kaldi-math.h:177-192 */
+      float x = tot, y = f[best], diff;
+      if (x < y) { diff = x - y; x = y; } else { diff = y - x; }
+      if (diff >= -15.9423847198486328125f) tot = x + log1pf(expf(diff));
+      else tot = x;
+    }
+    ans += tot;
+  }
+  free(used);
+  return ans;
 }
 
 /* Wall-clock helper for the cpu_baseline leg (seconds, monotonic). */

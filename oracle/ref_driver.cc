@@ -18,6 +18,7 @@
 // TransitionModel in front): hmm/transition-model.h needs an OpenFst header the
 // image lacks, so that class is not part of this build.
 #include <cstdlib>
+#include <fstream>
 #include <string>
 #include <vector>
 #include "base/kaldi-common.h"
@@ -172,6 +173,25 @@ int main(int argc, char *argv[]) {
                 << " left-context " << n.LeftContext() << " right-context "
                 << n.RightContext() << " num-components " << n.NumComponents()
                 << " priors-dim " << am.Priors().Dim() << "\n";
+      return 0;
+    } else if (cmd == "gmm-gselect") {
+      // DiagGmm::GaussianSelection of pdf argv[3]; one text line per frame: "key t idx..." and a
+      // final "TOTAL <sum of per-frame log-likelihoods>" line per utterance
+      AmDiagGmm am; ReadAm(argv[2], &am);
+      int32 pdf = atoi(argv[3]), num_gselect = atoi(argv[4]);
+      SequentialBaseFloatMatrixReader reader(argv[5]);
+      std::ofstream os(argv[6]);
+      os.precision(9);
+      for (; !reader.Done(); reader.Next()) {
+        std::vector<std::vector<int32> > gselect;
+        BaseFloat tot = am.GetPdf(pdf).GaussianSelection(reader.Value(), num_gselect, &gselect);
+        for (size_t t = 0; t < gselect.size(); t++) {
+          os << reader.Key() << " " << t;
+          for (size_t j = 0; j < gselect[t].size(); j++) os << " " << gselect[t][j];
+          os << "\n";
+        }
+        os << reader.Key() << " TOTAL " << tot << "\n";
+      }
       return 0;
     } else if (cmd == "compress-feats") {
       // writes every matrix as a CompressedMatrix ("CM" / "CM2" on disk)

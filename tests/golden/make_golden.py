@@ -15,6 +15,7 @@ Files written (all small):
   nnet_a.mdl nnet_a_feats.ark nnet_a_post.ark nnet_a_log.ark nnet_a_loglikes.ark nnet_a_post_nopad.ark
   nnet_b.mdl nnet_b_feats.ark nnet_b_post.ark  sigmoid / tanh / relu / mix-up sum-group network
   cm_feats.ark  cm_feats_expanded.ark          CompressedMatrix archive and its expansion
+  gsel.mdl gsel_feats.ark gsel_top5.txt        DiagGmm::GaussianSelection, 5 of 64 per frame
 """
 import os
 import sys
@@ -112,6 +113,12 @@ def main():
     ]
     pri_b = np.random.default_rng(5).dirichlet(np.ones(20)).astype(np.float32)
     nnet_case("nnet_b", comps_b, pri_b, [("m", rng.standard_normal((33, 10)).astype(np.float32))], full=False)
+    # Gaussian selection (DiagGmm::GaussianSelection) on a 64-component mixture.
+    ubm = synth.make_gmm(20, 1, 64, seed=4020)
+    write_am("gsel.mdl", ubm)
+    kio.write_ark(path("gsel_feats.ark"), [("g", synth.make_feats(ubm, 60, seed=4021))])
+    oracle.ref_driver("gmm-gselect", path("gsel.mdl"), "0", "5", "ark:" + path("gsel_feats.ark"),
+                      path("gsel_top5.txt"))
     # Compressed feature matrices as the reference writes them: "CM" (per-column percentiles +
     # bytes) for the 50- and 40-row matrices, "CM2" (16-bit) for the 7-row one; and what the
     # reference's Matrix<float>::Read makes of them.

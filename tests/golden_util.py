@@ -35,3 +35,15 @@ def load_ark(name):
 
 def load_vec(name):
     return kio.read_vector_file(gpath(name))
+
+
+def load_gselect(name):
+    """Returns ({key: [list of index lists per frame]}, {key: total log-likelihood})."""
+    sel, tot = {}, {}
+    for line in open(gpath(name)):
+        f = line.split()
+        if f[1] == "TOTAL":
+            tot[f[0]] = float(f[2])
+        else:
+            sel.setdefault(f[0], []).append([int(x) for x in f[2:]])
+    return sel, tot

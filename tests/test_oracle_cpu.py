@@ -186,3 +186,21 @@ def test_nnet_oracle_vs_live_reference(tmp_path):
     want = kio.read_ark(str(tmp_path / "o.ark"))[0][1]
     got = oracle.nnet_compute(comps, priors, feats, pad_input=True, mode=2, prob_scale=0.25)
     assert np.abs(got - want).max() <= 2e-5
+
+
+def test_gaussian_selection_vs_golden():
+    from golden_util import load_gselect
+    m = load_am_gmm("gsel.mdl")
+    sel, tot = load_gselect("gsel_top5.txt")
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    for key, feats in load_ark("gsel_feats.ark"):
+        scores = oracle.diag_gmm_loglikes_mat(gc, m["means_invvars"], m["inv_vars"], feats)
+        idx, total = oracle.gselect(scores, 5)
+        want = np.array(sel[key], dtype=np.int32)
+        # a pair of scores within rounding of each other may swap between BLAS and plain loops
+        differ = np.nonzero((idx != want).any(1))[0]
+        for t in differ:
+            assert sorted(idx[t]) == sorted(want[t]) or \
+                np.abs(np.sort(scores[t])[-6] - np.sort(scores[t])[-5]) < 1e-4
+        assert len(differ) <= 1
+        assert abs(total - tot[key]) <= 1e-3 * len(feats)
