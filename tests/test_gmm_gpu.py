@@ -274,3 +274,43 @@ def test_model_outside_fp16_range_uses_bf16x3_operands(amlike_device):
     gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
     want, _ = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"], feats)
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=TOL)
+
+
+def test_more_overflows_than_the_repair_list_holds(amlike_device):
+    """When the overflowed pairs outnumber the repair list, the wide-range kernel redoes the
+    launch (decided on the device); the answers must still match the oracle."""
+    rng = np.random.default_rng(15)
+    D, P, per = 40, 12, 4
+    G = P * per
+    means = rng.standard_normal((G, D)).astype(np.float32)
+    var = np.full((G, D), 100.0, np.float32)
+    var[1::per] = 0.01
+    # every pdf has its narrow Gaussian at the same place (near the origin, so that the fp32
+    # cancellation in x^2/var - 2 x mean/var + mean^2/var stays well inside the tolerance) ...
+    means[1::per] = 0.1 * means[1]
+    iv = (1.0 / var).astype(np.float32)
+    m = dict(weights=np.full(G, 1.0 / per, np.float32), inv_vars=iv,
+             means_invvars=(means * iv).astype(np.float32),
+             pdf_offsets=np.arange(0, G + 1, per, dtype=np.int32), dim=D)
+    T = 1200
+    # ... and every frame sits there: each (frame, pdf) pair overflows the reference-relative sum
+    feats = (means[1] + 0.05 * rng.standard_normal((T, D))).astype(np.float32)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    got = am.LogLikelihoods(feats)
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    per_gauss = oracle.diag_gmm_loglikes_mat(gc, m["means_invvars"], m["inv_vars"], feats)
+    spread = per_gauss.reshape(T, P, per).max(2) - per_gauss.reshape(T, P, per)[:, :, 0]
+    assert (spread > 100).sum() > 4096  # more than the list's minimum capacity
+    want, st = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"], feats)
+    assert st == 0
+    np.testing.assert_allclose(got, want, rtol=3e-6, atol=TOL)
+
+
+@pytest.mark.parametrize("per", [1, 2, 3])
+def test_many_tiny_pdfs(amlike_device, per):
+    P = 700
+    m = synth.make_gmm(40, P, P * per, seed=300 + per, equal_sizes=True)
+    assert int(m["pdf_offsets"][-1]) == P * per
+    feats = synth.make_feats(m, 97, seed=301)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    _check(m, feats, am.LogLikelihoods(feats))
