@@ -13,6 +13,7 @@
 #ifndef AMLIKE_H_
 #define AMLIKE_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -28,6 +29,7 @@ extern "C" {
 #define AMLIKE_EHIP 4       /* a HIP runtime call failed (CU_SAFE_CALL analogue, cudamatrix/cu-common.h:38-45) */
 #define AMLIKE_EOOM 5       /* device allocation failed (cudamatrix/cu-device.cc:640-652) */
 #define AMLIKE_ENODEV 6     /* no usable GPU (cudamatrix/cu-device.cc:99-138) */
+#define AMLIKE_EBUSY 7      /* both submission slots of the handle are in flight: wait for one first */
 
 typedef struct amlike_gmm amlike_gmm_t;   /* packed AmDiagGmm resident in HBM */
 typedef struct amlike_nnet amlike_nnet_t; /* nnet2 forward pipeline resident in HBM */
@@ -44,6 +46,14 @@ const char *amlike_last_error(void);
 
 /* Number of visible devices (0 when there is none). */
 int amlike_device_count(void);
+
+/* Page-locked host memory for the buffers given to the *_submit calls below (and, if the
+ * caller likes, to the synchronous host-pointer calls): copies to and from such memory run at
+ * the full rate of the link and overlap with kernels.  The reference copies from ordinary
+ * memory (CuMatrix::CopyToMat, cudamatrix/cu-matrix.cc:387-412); this pair has no counterpart
+ * there. */
+int amlike_host_alloc(size_t bytes, void **ptr);
+int amlike_host_free(void *ptr);
 
 /* ---- diagonal-GMM acoustic model ----------------------------------------- */
 
@@ -85,6 +95,21 @@ int32_t amlike_gmm_dim(const amlike_gmm_t *gmm);
  * Returns AMLIKE_ENONFINITE if any output is NaN/Inf (the output is still written). */
 int amlike_gmm_score(amlike_gmm_t *gmm, const float *feats, int32_t T, int32_t ld,
                      int32_t feat_dim, float log_sum_exp_prune, float *out, int32_t ldo);
+
+/* The same work, not waited for: the copy in, the kernels and the copy out are enqueued and the
+ * call returns a ticket; amlike_gmm_score_wait(ticket) blocks until `out` is complete and
+ * returns what amlike_gmm_score would have.  A handle takes two submissions at a time
+ * (AMLIKE_EBUSY beyond that); they complete in submission order, and the copy out of one
+ * overlaps the kernels of the next.  This is what lets a decoder work on utterance k while
+ * utterance k+1 is scored (the reference computes likelihoods inside the decoder's loop,
+ * gmm/decodable-am-diag-gmm.cc:28-72, so it has no such call).  feats and out must stay valid
+ * until the wait returns; page-locked buffers (amlike_host_alloc) make the call truly
+ * asynchronous, ordinary memory works but may block in the copies.
+ * At most 2^30 output elements (T x num_pdfs) per submission. */
+int amlike_gmm_score_submit(amlike_gmm_t *gmm, const float *feats, int32_t T, int32_t ld,
+                            int32_t feat_dim, float log_sum_exp_prune, float *out, int32_t ldo,
+                            int32_t *ticket);
+int amlike_gmm_score_wait(amlike_gmm_t *gmm, int32_t ticket);
 
 /* Device-pointer form: feats/out are device memory, the work is enqueued on
  * `stream` (a hipStream_t, or NULL for the default stream) and NOT waited for.
@@ -187,6 +212,11 @@ int32_t amlike_nnet_right_context(const amlike_nnet_t *nnet); /* Nnet::RightCont
 int amlike_nnet_compute(amlike_nnet_t *nnet, const float *feats, int32_t T, int32_t ld,
                         int32_t pad_input, int32_t mode, float prob_scale, float *out,
                         int32_t ldo);
+/* Submit / wait form of amlike_nnet_compute, with the rules of amlike_gmm_score_submit. */
+int amlike_nnet_compute_submit(amlike_nnet_t *nnet, const float *feats, int32_t T, int32_t ld,
+                               int32_t pad_input, int32_t mode, float prob_scale, float *out,
+                               int32_t ldo, int32_t *ticket);
+int amlike_nnet_compute_wait(amlike_nnet_t *nnet, int32_t ticket);
 /* Device-pointer, asynchronous form. */
 int amlike_nnet_compute_dev(amlike_nnet_t *nnet, const float *d_feats, int32_t T, int32_t ld,
                             int32_t pad_input, int32_t mode, float prob_scale, float *d_out,

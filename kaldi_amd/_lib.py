@@ -10,7 +10,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int32, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libamlike.so")
 
-OK, EINVAL, EDIM, ENONFINITE, EHIP, EOOM, ENODEV = range(7)
+OK, EINVAL, EDIM, ENONFINITE, EHIP, EOOM, ENODEV, EBUSY = range(8)
 
 _lib = None
 
@@ -37,6 +37,12 @@ def _declare(lib):
         "amlike_init": (ctypes.c_int, [ctypes.c_int]),
         "amlike_last_error": (c_char_p, []),
         "amlike_device_count": (ctypes.c_int, []),
+        "amlike_host_alloc": (ctypes.c_int, [ctypes.c_size_t, POINTER(c_void_p)]),
+        "amlike_host_free": (ctypes.c_int, [c_void_p]),
+        "amlike_gmm_score_submit": (ctypes.c_int, [c_void_p, fp, c_int32, c_int32, c_int32, c_float, fp, c_int32, ip]),
+        "amlike_gmm_score_wait": (ctypes.c_int, [c_void_p, c_int32]),
+        "amlike_nnet_compute_submit": (ctypes.c_int, [c_void_p, fp, c_int32, c_int32, c_int32, c_int32, c_float, fp, c_int32, ip]),
+        "amlike_nnet_compute_wait": (ctypes.c_int, [c_void_p, c_int32]),
         "amlike_gmm_create": (ctypes.c_int, [fp, fp, fp, ip, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
         "amlike_gmm_destroy": (ctypes.c_int, [c_void_p]),
         "amlike_gmm_compute_gconsts": (ctypes.c_int, [fp, fp, fp, c_int32, c_int32, fp, ip]),
@@ -90,6 +96,31 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         EXPORTS = sorted(_declare(_lib).keys())
     return _lib
+
+
+class PinnedArray:
+    """A float32 [rows x cols] array in page-locked host memory (amlike_host_alloc); `.a` is
+    the numpy view, valid until close()."""
+
+    def __init__(self, rows, cols):
+        import numpy as np
+        self._p = c_void_p()
+        n = max(1, int(rows) * int(cols))
+        check(lib().amlike_host_alloc(n * 4, ctypes.byref(self._p)))
+        buf = (c_float * n).from_address(self._p.value)
+        self.a = np.frombuffer(buf, dtype=np.float32, count=int(rows) * int(cols)).reshape(int(rows), int(cols))
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self.a = None
+            lib().amlike_host_free(self._p)
+            self._p = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def check(code):

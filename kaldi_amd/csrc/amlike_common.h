@@ -30,6 +30,19 @@ struct DeviceBuffer {
   void Free();
 };
 
+// One submission of the asynchronous host-pointer entry points (*_submit / *_wait): its own
+// device input and output buffers, the event the output copy waits for, the event the
+// caller waits for, and a pinned word the non-finite flag lands in.
+struct AsyncSlot {
+  hipEvent_t computed = nullptr, done = nullptr;
+  int *h_flag = nullptr;
+  DeviceBuffer in, out;
+  int32_t ticket = -1;  // -1: free
+  int Prepare();        // creates the events and the flag word on first use
+  void Release();
+};
+constexpr int kAsyncSlots = 2;
+
 // fp32 -> bf16, round to nearest even (inf / nan: truncated).
 static inline uint16_t Bf16Rne(float x) {
   uint32_t u;

@@ -49,6 +49,28 @@ void DeviceBuffer::Free() {
   bytes = 0;
 }
 
+int AsyncSlot::Prepare() {
+  if (!computed) AMLIKE_HIP(hipEventCreateWithFlags(&computed, hipEventDisableTiming));
+  if (!done) AMLIKE_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  if (!h_flag) {
+    AMLIKE_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_flag), sizeof(int), hipHostMallocDefault));
+    *h_flag = 0;
+  }
+  return AMLIKE_OK;
+}
+
+void AsyncSlot::Release() {
+  if (ticket >= 0 && done) (void)hipEventSynchronize(done);
+  if (computed) (void)hipEventDestroy(computed);
+  if (done) (void)hipEventDestroy(done);
+  if (h_flag) (void)hipHostFree(h_flag);
+  computed = done = nullptr;
+  h_flag = nullptr;
+  in.Free();
+  out.Free();
+  ticket = -1;
+}
+
 }  // namespace amlike
 
 extern "C" {
@@ -82,5 +104,26 @@ int amlike_init(int device) {
 }
 
 const char *amlike_last_error(void) { return amlike::LastError(); }
+
+int amlike_host_alloc(size_t bytes, void **ptr) {
+  if (!ptr || bytes == 0) {
+    amlike::SetError("amlike_host_alloc: invalid argument");
+    return AMLIKE_EINVAL;
+  }
+  *ptr = nullptr;
+  hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *ptr = nullptr;
+    amlike::SetError("hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    return AMLIKE_EOOM;
+  }
+  return AMLIKE_OK;
+}
+
+int amlike_host_free(void *ptr) {
+  if (ptr) AMLIKE_HIP(hipHostFree(ptr));
+  return AMLIKE_OK;
+}
 
 }  // extern "C"

@@ -2,8 +2,9 @@
 // binary (/root/reference/src/gmmbin/gmm-compute-likes.cc:30-89); the frame x pdf loop
 // (:71-77) runs on the GPU through libamlike.  Extra options: --device, and
 // --frames-per-batch (utterances are scored together in batches of about that many
-// frames and written back in input order).
+// frames, two batches in flight, and written back in input order).
 #include <chrono>
+#include <deque>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -11,6 +12,7 @@
 #include "../host/gmm_model.h"
 #include "../host/kaldi_io.h"
 #include "../host/parse_options.h"
+#include "../host/pipeline.h"
 
 int main(int argc, char *argv[]) {
   using namespace kaldi_amd;
@@ -41,13 +43,36 @@ int main(int argc, char *argv[]) {
     }
     MatrixWriter loglikes_writer(po.GetArg(3));
     SequentialMatrixReader feature_reader(po.GetArg(2));
+    const auto t_pack = std::chrono::steady_clock::now();
+    am_gmm.Engine();  // packs the model and uploads it (once per process)
     const auto t0 = std::chrono::steady_clock::now();
     int32 num_done = 0;
     long long num_frames = 0;
-    std::vector<std::string> keys;
-    std::vector<int32> rows;
-    Matrix batch, likes;
+    // Utterances are packed into batches of about frames_per_batch frames; two batches are
+    // in flight, so reading and packing batch k+1 and writing batch k-1 overlap the GPU's
+    // work on batch k.
+    struct Batch {
+      std::vector<std::string> keys;
+      std::vector<int32> rows;
+    };
+    LikelihoodPipeline pipe(am_gmm, log_sum_exp_prune);
+    std::deque<Batch> in_flight;
+    auto drain_one = [&]() {
+      const PinnedMatrix &likes = pipe.Front(nullptr);
+      const Batch &b = in_flight.front();
+      int32 r0 = 0;
+      for (size_t u = 0; u < b.keys.size(); ++u) {
+        loglikes_writer.Write(b.keys[u], likes.RowData(r0), b.rows[u], likes.NumCols(), likes.Stride());
+        r0 += b.rows[u];
+        num_done++;
+      }
+      num_frames += r0;
+      pipe.Pop();
+      in_flight.pop_front();
+    };
+    Batch cur;
     std::vector<Matrix> pending;
+    Matrix batch;
     auto flush = [&]() {
       if (pending.empty()) return;
       int32 total = 0;
@@ -61,24 +86,17 @@ int main(int argc, char *argv[]) {
           std::copy(m.RowData(r), m.RowData(r) + m.NumCols(), batch.RowData(r0 + r));
         r0 += m.NumRows();
       }
-      am_gmm.LogLikelihoods(batch, &likes, log_sum_exp_prune);
-      r0 = 0;
-      for (size_t u = 0; u < pending.size(); ++u) {
-        Matrix out(pending[u].NumRows(), am_gmm.NumPdfs());
-        for (int32 r = 0; r < out.NumRows(); ++r)
-          std::copy(likes.RowData(r0 + r), likes.RowData(r0 + r) + out.NumCols(), out.RowData(r));
-        r0 += out.NumRows();
-        loglikes_writer.Write(keys[u], out);
-        num_done++;
-      }
-      num_frames += total;
+      if (pipe.Full()) drain_one();
+      pipe.Submit("", batch);
+      in_flight.push_back(cur);
+      cur = Batch();
       pending.clear();
-      keys.clear();
     };
     int32 in_batch = 0;
     for (; !feature_reader.Done(); feature_reader.Next()) {
       if (feature_reader.Value().NumRows() == 0) continue;
-      keys.push_back(feature_reader.Key());
+      cur.keys.push_back(feature_reader.Key());
+      cur.rows.push_back(feature_reader.Value().NumRows());
       pending.push_back(feature_reader.Value());
       in_batch += feature_reader.Value().NumRows();
       if (in_batch >= frames_per_batch) {
@@ -87,9 +105,12 @@ int main(int argc, char *argv[]) {
       }
     }
     flush();
+    while (!in_flight.empty()) drain_one();
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::cerr << "LOG (gmm-compute-likes) gmm-compute-likes: computed likelihoods for " << num_done
               << " utterances.\n";
+    std::cerr << "LOG (gmm-compute-likes) model packed and uploaded in "
+              << std::chrono::duration<double>(t0 - t_pack).count() << " s\n";
     std::cerr << "LOG (gmm-compute-likes) " << num_frames << " frames in " << secs << " s ("
               << (secs > 0 ? num_frames / secs : 0.0) << " frames/s including file I/O)\n";
     return 0;

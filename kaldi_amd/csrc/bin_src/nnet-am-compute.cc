@@ -7,6 +7,7 @@
 #include "../host/kaldi_io.h"
 #include "../host/nnet_model.h"
 #include "../host/parse_options.h"
+#include "../host/pipeline.h"
 
 int main(int argc, char *argv[]) {
   using namespace kaldi_amd;
@@ -52,6 +53,16 @@ int main(int argc, char *argv[]) {
     SequentialMatrixReader feature_reader(po.GetArg(2));
     MatrixWriter writer(po.GetArg(3));
     const int mode = divide_by_priors ? AMLIKE_NNET_LOGLIKES : apply_log ? AMLIKE_NNET_LOG : AMLIKE_NNET_POSTERIORS;
+    // Two utterances in flight: reading utterance k+1 and writing utterance k-1 overlap the
+    // GPU's work on utterance k.
+    LikelihoodPipeline pipe(am_nnet, pad_input, mode, prob_scale);
+    auto drain_one = [&]() {
+      std::string utt;
+      const PinnedMatrix &output = pipe.Front(&utt);
+      writer.Write(utt, output.Data(), output.NumRows(), output.NumCols(), output.Stride());
+      pipe.Pop();
+      num_done++;
+    };
     for (; !feature_reader.Done(); feature_reader.Next()) {
       const std::string utt = feature_reader.Key();
       const Matrix &feats = feature_reader.Value();
@@ -62,12 +73,11 @@ int main(int argc, char *argv[]) {
                   << " because output would be empty.\n";
         continue;
       }
-      Matrix output;
-      NnetComputation(am_nnet, feats, pad_input, mode, prob_scale, &output);
-      writer.Write(utt, output);
+      if (pipe.Full()) drain_one();
+      pipe.Submit(utt, feats);
       num_frames += feats.NumRows();
-      num_done++;
     }
+    while (!pipe.Empty()) drain_one();
     std::cerr << "LOG (nnet-am-compute) Processed " << num_done << " feature files, " << num_frames
               << " frames of input were processed.\n";
     return (num_done == 0 ? 1 : 0);

@@ -1228,6 +1228,9 @@ struct amlike_gmm {
   int32_t *d_offsets = nullptr;  // [num_pdfs + 1]
   std::vector<int32_t> pdf_offsets;
   hipStream_t stream = nullptr;  // used by the host-pointer entry points
+  hipStream_t copy_stream = nullptr;  // submit / wait: the copies out, behind the kernels
+  AsyncSlot slots[kAsyncSlots];
+  int32_t next_ticket = 0;
   DeviceBuffer ws_feats, ws_out, ws_part, ws_pad, ws_expand, ws_expand_safe, ws_fix, ws_gauss;
   std::mutex mu;
   std::string info;
@@ -1835,6 +1838,8 @@ int amlike_gmm_destroy(amlike_gmm_t *g) {
   g->ws_part.Free();
   g->ws_pad.Free();
   g->ws_expand.Free();
+  for (AsyncSlot &s : g->slots) s.Release();
+  if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
   if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
   return AMLIKE_OK;
@@ -1943,6 +1948,88 @@ int amlike_gmm_score(amlike_gmm_t *g, const float *feats, int32_t T, int32_t ld,
     else if (rc != AMLIKE_OK) return rc;
   }
   return status;
+}
+
+int amlike_gmm_score_submit(amlike_gmm_t *g, const float *feats, int32_t T, int32_t ld,
+                            int32_t feat_dim, float log_sum_exp_prune, float *out, int32_t ldo,
+                            int32_t *ticket) {
+  int rc = CheckScoreArgs(g, T, ld, feat_dim, ldo, feats, out);
+  if (rc != AMLIKE_OK) return rc;
+  const int P = g->num_pdfs;
+  if (!ticket || (size_t)T * P > ((size_t)1 << 30)) {
+    SetError("amlike_gmm_score_submit: %s", ticket ? "more than 2^30 outputs in one submission" : "null ticket");
+    return AMLIKE_EINVAL;
+  }
+  std::lock_guard<std::mutex> lock(g->mu);
+  AsyncSlot *s = nullptr;
+  for (AsyncSlot &c : g->slots)
+    if (c.ticket < 0 && !s) s = &c;
+  if (!s) {
+    SetError("amlike_gmm_score_submit: %d submissions in flight, wait for one first", kAsyncSlots);
+    return AMLIKE_EBUSY;
+  }
+  if (!g->copy_stream) AMLIKE_HIP(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+  rc = s->Prepare();
+  if (rc != AMLIKE_OK) return rc;
+  const int ldp = (g->dim + 3) & ~3;
+  const bool feats_1d = (size_t)ld <= (size_t)2 * ldp + 8;
+  const int dld = feats_1d ? ld : ldp;
+  rc = s->in.Reserve((size_t)T * dld * sizeof(float));
+  if (rc != AMLIKE_OK) return rc;
+  rc = s->out.Reserve((size_t)T * P * sizeof(float));
+  if (rc != AMLIKE_OK) return rc;
+  float *df = static_cast<float *>(s->in.ptr), *dout = static_cast<float *>(s->out.ptr);
+  if (feats_1d)
+    AMLIKE_HIP(hipMemcpyAsync(df, feats, ((size_t)(T - 1) * ld + g->dim) * sizeof(float),
+                              hipMemcpyHostToDevice, g->stream));
+  else
+    AMLIKE_HIP(hipMemcpy2DAsync(df, (size_t)dld * sizeof(float), feats, (size_t)ld * sizeof(float),
+                                (size_t)g->dim * sizeof(float), T, hipMemcpyHostToDevice, g->stream));
+  rc = amlike_gmm_score_dev(g, df, T, dld, feat_dim, log_sum_exp_prune, dout, P, g->stream);
+  if (rc != AMLIKE_OK) return rc;
+  AMLIKE_HIP(hipMemcpyAsync(s->h_flag, g->d_flag, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+  AMLIKE_HIP(hipMemsetAsync(g->d_flag, 0, sizeof(int), g->stream));
+  AMLIKE_HIP(hipEventRecord(s->computed, g->stream));
+  AMLIKE_HIP(hipStreamWaitEvent(g->copy_stream, s->computed, 0));
+  if (ldo == P)
+    AMLIKE_HIP(hipMemcpyAsync(out, dout, (size_t)T * P * sizeof(float), hipMemcpyDeviceToHost,
+                              g->copy_stream));
+  else
+    AMLIKE_HIP(hipMemcpy2DAsync(out, (size_t)ldo * sizeof(float), dout, (size_t)P * sizeof(float),
+                                (size_t)P * sizeof(float), T, hipMemcpyDeviceToHost, g->copy_stream));
+  AMLIKE_HIP(hipEventRecord(s->done, g->copy_stream));
+  s->ticket = g->next_ticket;
+  g->next_ticket = (g->next_ticket + 1) & 0x3fffffff;
+  *ticket = s->ticket;
+  return AMLIKE_OK;
+}
+
+int amlike_gmm_score_wait(amlike_gmm_t *g, int32_t ticket) {
+  if (!g || ticket < 0) {
+    SetError("amlike_gmm_score_wait: invalid argument");
+    return AMLIKE_EINVAL;
+  }
+  AsyncSlot *s = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g->mu);
+    for (AsyncSlot &c : g->slots)
+      if (c.ticket == ticket) s = &c;
+  }
+  if (!s) {
+    SetError("amlike_gmm_score_wait: ticket %d is not in flight", ticket);
+    return AMLIKE_EINVAL;
+  }
+  AMLIKE_HIP(hipEventSynchronize(s->done));
+  const int flag = *s->h_flag;
+  {
+    std::lock_guard<std::mutex> lock(g->mu);
+    s->ticket = -1;
+  }
+  if (flag) {
+    SetError("Invalid answer (overflow or invalid variances/features?)");
+    return AMLIKE_ENONFINITE;
+  }
+  return AMLIKE_OK;
 }
 
 int amlike_gmm_gauss_loglikes_dev(amlike_gmm_t *g, int32_t pdf_begin, int32_t pdf_end,

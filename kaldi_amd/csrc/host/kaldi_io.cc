@@ -375,26 +375,37 @@ void Matrix::Read(std::istream &is, bool binary) {
   }
 }
 
-void Matrix::Write(std::ostream &os, bool binary) const {
+// matrix/kaldi-matrix.cc:1118-1144 for rows given by pointer and stride.
+void WriteMatrixData(std::ostream &os, bool binary, const float *data, int32 rows, int32 cols,
+                     int32 stride) {
   if (binary) {
     WriteToken(os, binary, "FM");
-    WriteBasicType(os, binary, rows_);
-    WriteBasicType(os, binary, cols_);
-    for (int32 r = 0; r < rows_; ++r)
-      os.write(reinterpret_cast<const char *>(RowData(r)), static_cast<std::streamsize>(4) * cols_);
+    WriteBasicType(os, binary, rows);
+    WriteBasicType(os, binary, cols);
+    if (stride == cols) {
+      os.write(reinterpret_cast<const char *>(data), static_cast<std::streamsize>(4) * cols * rows);
+    } else {
+      for (int32 r = 0; r < rows; ++r)
+        os.write(reinterpret_cast<const char *>(data + static_cast<size_t>(r) * stride),
+                 static_cast<std::streamsize>(4) * cols);
+    }
   } else {
-    if (cols_ == 0) {
+    if (cols == 0) {
       os << " [ ]\n";
     } else {
       os << " [";
-      for (int32 r = 0; r < rows_; ++r) {
+      for (int32 r = 0; r < rows; ++r) {
         os << "\n  ";
-        for (int32 c = 0; c < cols_; ++c) os << (*this)(r, c) << " ";
+        for (int32 c = 0; c < cols; ++c) os << data[static_cast<size_t>(r) * stride + c] << " ";
       }
       os << "]\n";
     }
   }
   if (os.fail()) KaldiErr("Failed to write matrix to stream");
+}
+
+void Matrix::Write(std::ostream &os, bool binary) const {
+  WriteMatrixData(os, binary, data_.data(), rows_, cols_, stride_);
 }
 
 // ---- files ---------------------------------------------------------------------
@@ -625,10 +636,15 @@ MatrixWriter::~MatrixWriter() {
 }
 
 void MatrixWriter::Write(const std::string &key, const Matrix &m) {
+  Write(key, m.Data(), m.NumRows(), m.NumCols(), m.Stride());
+}
+
+void MatrixWriter::Write(const std::string &key, const float *data, int32 rows, int32 cols,
+                         int32 stride) {
   *os_ << key << ' ';
   if (scp_) *scp_ << key << ' ' << ark_name_ << ':' << os_->tellp() << '\n';
   InitKaldiOutputStream(*os_, binary_);
-  m.Write(*os_, binary_);
+  WriteMatrixData(*os_, binary_, data, rows, cols, stride);
   if (os_->fail()) KALDI_AMD_ERR("Write failure for key " << key);
 }
 

@@ -168,11 +168,16 @@ class SequentialMatrixReader {
 };
 
 // wspecifier: "ark:FILE", "ark,t:FILE", "ark:-", "ark,scp:ARK,SCP".  Mirrors BaseFloatMatrixWriter.
+void WriteMatrixData(std::ostream &os, bool binary, const float *data, int32 rows, int32 cols,
+                     int32 stride);
+
 class MatrixWriter {
  public:
   explicit MatrixWriter(const std::string &wspecifier);
   ~MatrixWriter();
   void Write(const std::string &key, const Matrix &m);
+  // rows given by pointer and stride (no intermediate Matrix)
+  void Write(const std::string &key, const float *data, int32 rows, int32 cols, int32 stride);
 
  private:
   bool binary_ = true;

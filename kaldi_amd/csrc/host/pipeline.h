@@ -1,0 +1,101 @@
+// Scoring one utterance ahead of its consumer.
+//
+// In the reference a GMM decodable computes a likelihood when the decoder asks for it
+// (/root/reference/src/gmm/decodable-am-diag-gmm.cc:28-72) and DecodableAmNnet computes the
+// whole utterance in its constructor (/root/reference/src/nnet2/decodable-am-nnet.h:57-73);
+// either way the decoder waits for the acoustic model.  Here the acoustic model of utterance
+// k+1 runs on the GPU while the CPU decodes utterance k out of a finished matrix, which it
+// sees through DecodableMatrixScaledMapped, the class the reference's matrix-fed decoders
+// use (/root/reference/src/decoder/decodable-matrix.h:33-84,
+//  /root/reference/src/bin/latgen-faster-mapped.cc:116).
+#ifndef KALDI_AMD_CSRC_HOST_PIPELINE_H_
+#define KALDI_AMD_CSRC_HOST_PIPELINE_H_
+
+#include <string>
+
+#include "gmm_model.h"
+#include "nnet_model.h"
+
+namespace kaldi_amd {
+
+// A float matrix in page-locked host memory (amlike_host_alloc); grows, never shrinks.
+class PinnedMatrix {
+ public:
+  PinnedMatrix() {}
+  ~PinnedMatrix();
+  PinnedMatrix(const PinnedMatrix &) = delete;
+  PinnedMatrix &operator=(const PinnedMatrix &) = delete;
+  void Resize(int32 rows, int32 cols);  // contents undefined afterwards
+  int32 NumRows() const { return rows_; }
+  int32 NumCols() const { return cols_; }
+  int32 Stride() const { return cols_; }
+  float *Data() { return data_; }
+  const float *Data() const { return data_; }
+  float *RowData(int32 r) { return data_ + static_cast<size_t>(r) * cols_; }
+  const float *RowData(int32 r) const { return data_ + static_cast<size_t>(r) * cols_; }
+  float operator()(int32 r, int32 c) const { return RowData(r)[c]; }
+  void CopyFromMat(const Matrix &m);
+  void CopyToMat(Matrix *m) const;
+
+ private:
+  float *data_ = nullptr;
+  size_t capacity_ = 0;  // floats
+  int32 rows_ = 0, cols_ = 0;
+};
+
+// decoder/decodable-matrix.h:33-84 over a matrix this class does not own:
+// LogLikelihood(frame, tid) = scale * likes(frame, TransitionIdToPdf(tid)).
+class DecodableMatrixScaledMapped : public DecodableInterface {
+ public:
+  DecodableMatrixScaledMapped(const TransitionModel &tm, const PinnedMatrix &likes, BaseFloat scale);
+  BaseFloat LogLikelihood(int32 frame, int32 tid) override {
+    return scale_ * likes_(frame, trans_model_.TransitionIdToPdf(tid));
+  }
+  int32 NumFramesReady() const override { return likes_.NumRows(); }
+  int32 NumIndices() const override { return trans_model_.NumTransitionIds(); }
+  bool IsLastFrame(int32 frame) const override { return frame == likes_.NumRows() - 1; }
+
+ private:
+  const TransitionModel &trans_model_;
+  const PinnedMatrix &likes_;
+  BaseFloat scale_;
+};
+
+// Up to two utterances in flight on one model: Submit() copies the features to page-locked
+// memory and enqueues copy-in, kernels and copy-out; Front() blocks until the oldest one is
+// complete.  Results come back in submission order.
+class LikelihoodPipeline {
+ public:
+  // [T x NumPdfs] log-likelihoods of a GMM (unscaled, as gmm-compute-likes writes them).
+  explicit LikelihoodPipeline(const AmDiagGmm &am, BaseFloat log_sum_exp_prune = -1.0);
+  // nnet2 output in one of the AMLIKE_NNET_* modes (AMLIKE_NNET_LOGLIKES = DecodableAmNnet).
+  LikelihoodPipeline(const nnet2::AmNnet &am, bool pad_input, int mode, BaseFloat prob_scale);
+  ~LikelihoodPipeline();
+  bool Full() const { return count_ == 2; }
+  bool Empty() const { return count_ == 0; }
+  void Submit(const std::string &key, const Matrix &feats);
+  // The oldest submission, waited for; valid until Pop().  Throws what the synchronous call
+  // would have thrown ("Invalid answer ...").
+  const PinnedMatrix &Front(std::string *key);
+  void Pop();
+
+ private:
+  struct Slot {
+    PinnedMatrix in, out;
+    std::string key;
+    int32 ticket = -1;
+    bool waited = false;
+  };
+  amlike_gmm_t *gmm_ = nullptr;
+  amlike_nnet_t *nnet_ = nullptr;
+  int32 num_pdfs_ = 0, dim_ = 0, ctx_ = 0;
+  BaseFloat prune_ = -1.0f, prob_scale_ = 1.0f;
+  bool pad_input_ = true;
+  int mode_ = 0;
+  Slot slots_[2];
+  int head_ = 0, count_ = 0;
+};
+
+}  // namespace kaldi_amd
+
+#endif  // KALDI_AMD_CSRC_HOST_PIPELINE_H_

@@ -951,6 +951,10 @@ struct amlike_nnet {
   bool gemm_inline_split = false;  // AMLIKE_NNET_GEMM=inline: bf16x3 GEMM that splits X in its k-loop
   float *d_log_priors = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // submit / wait: the copies out, behind the kernels
+  AsyncSlot slots[kAsyncSlots];
+  std::vector<UttMap> slot_utts[kAsyncSlots];  // the row maps a submission's upload reads
+  int32_t next_ticket = 0;
   DeviceBuffer ws_a, ws_b, ws_in, ws_out, ws_utts, ws_planes;
   std::vector<UttMap> h_utts;
   std::mutex mu;
@@ -974,6 +978,8 @@ static void FreeNnet(amlike_nnet *n) {
   n->ws_out.Free();
   n->ws_utts.Free();
   n->ws_planes.Free();
+  for (AsyncSlot &s : n->slots) s.Release();
+  if (n->copy_stream) (void)hipStreamDestroy(n->copy_stream);
   if (n->stream) (void)hipStreamDestroy(n->stream);
   delete n;
 }
@@ -1614,6 +1620,93 @@ int amlike_nnet_compute(amlike_nnet_t *n, const float *feats, int32_t T, int32_t
                                 (size_t)n->output_dim * sizeof(float), t_out, hipMemcpyDeviceToHost,
                                 n->stream));
   AMLIKE_HIP(hipStreamSynchronize(n->stream));
+  return AMLIKE_OK;
+}
+
+int amlike_nnet_compute_submit(amlike_nnet_t *n, const float *feats, int32_t T, int32_t ld,
+                               int32_t pad_input, int32_t mode, float prob_scale, float *out,
+                               int32_t ldo, int32_t *ticket) {
+  if (!n || !feats || !out || !ticket || T <= 0 || ld < n->input_dim || ldo < n->output_dim) {
+    SetError("amlike_nnet_compute_submit: invalid argument");
+    return AMLIKE_EINVAL;
+  }
+  const int t_out = pad_input ? T : T - n->left - n->right;
+  if (t_out <= 0) {
+    SetError("amlike_nnet_compute: %d frames give empty output", T);
+    return AMLIKE_EINVAL;
+  }
+  if ((size_t)t_out * n->output_dim > ((size_t)1 << 30)) {
+    SetError("amlike_nnet_compute_submit: more than 2^30 outputs in one submission");
+    return AMLIKE_EINVAL;
+  }
+  std::lock_guard<std::mutex> lock(n->mu);
+  int si = -1;
+  for (int i = 0; i < kAsyncSlots; ++i)
+    if (n->slots[i].ticket < 0 && si < 0) si = i;
+  if (si < 0) {
+    SetError("amlike_nnet_compute_submit: %d submissions in flight, wait for one first", kAsyncSlots);
+    return AMLIKE_EBUSY;
+  }
+  AsyncSlot *s = &n->slots[si];
+  if (!n->copy_stream) AMLIKE_HIP(hipStreamCreateWithFlags(&n->copy_stream, hipStreamNonBlocking));
+  int rc = s->Prepare();
+  if (rc != AMLIKE_OK) return rc;
+  const bool feats_1d = (size_t)ld <= (size_t)2 * n->input_dim + 8;
+  const int dld = feats_1d ? ld : n->input_dim;
+  rc = s->in.Reserve((size_t)T * dld * sizeof(float));
+  if (rc != AMLIKE_OK) return rc;
+  rc = s->out.Reserve((size_t)t_out * n->output_dim * sizeof(float));
+  if (rc != AMLIKE_OK) return rc;
+  float *din = static_cast<float *>(s->in.ptr), *dout = static_cast<float *>(s->out.ptr);
+  if (feats_1d)
+    AMLIKE_HIP(hipMemcpyAsync(din, feats, ((size_t)(T - 1) * ld + n->input_dim) * sizeof(float),
+                              hipMemcpyHostToDevice, n->stream));
+  else
+    AMLIKE_HIP(hipMemcpy2DAsync(din, (size_t)n->input_dim * sizeof(float), feats,
+                                (size_t)ld * sizeof(float), (size_t)n->input_dim * sizeof(float), T,
+                                hipMemcpyHostToDevice, n->stream));
+  // the row maps are uploaded from host memory that must outlive the copy: each slot keeps
+  // its own
+  std::swap(n->h_utts, n->slot_utts[si]);
+  rc = amlike_nnet_compute_dev(n, din, T, dld, pad_input, mode, prob_scale, dout, n->output_dim,
+                               n->stream);
+  std::swap(n->h_utts, n->slot_utts[si]);
+  if (rc != AMLIKE_OK) return rc;
+  AMLIKE_HIP(hipEventRecord(s->computed, n->stream));
+  AMLIKE_HIP(hipStreamWaitEvent(n->copy_stream, s->computed, 0));
+  if (ldo == n->output_dim)
+    AMLIKE_HIP(hipMemcpyAsync(out, dout, (size_t)t_out * n->output_dim * sizeof(float),
+                              hipMemcpyDeviceToHost, n->copy_stream));
+  else
+    AMLIKE_HIP(hipMemcpy2DAsync(out, (size_t)ldo * sizeof(float), dout,
+                                (size_t)n->output_dim * sizeof(float),
+                                (size_t)n->output_dim * sizeof(float), t_out, hipMemcpyDeviceToHost,
+                                n->copy_stream));
+  AMLIKE_HIP(hipEventRecord(s->done, n->copy_stream));
+  s->ticket = n->next_ticket;
+  n->next_ticket = (n->next_ticket + 1) & 0x3fffffff;
+  *ticket = s->ticket;
+  return AMLIKE_OK;
+}
+
+int amlike_nnet_compute_wait(amlike_nnet_t *n, int32_t ticket) {
+  if (!n || ticket < 0) {
+    SetError("amlike_nnet_compute_wait: invalid argument");
+    return AMLIKE_EINVAL;
+  }
+  AsyncSlot *s = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(n->mu);
+    for (AsyncSlot &c : n->slots)
+      if (c.ticket == ticket) s = &c;
+  }
+  if (!s) {
+    SetError("amlike_nnet_compute_wait: ticket %d is not in flight", ticket);
+    return AMLIKE_EINVAL;
+  }
+  AMLIKE_HIP(hipEventSynchronize(s->done));
+  std::lock_guard<std::mutex> lock(n->mu);
+  s->ticket = -1;
   return AMLIKE_OK;
 }
 

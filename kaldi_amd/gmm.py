@@ -95,6 +95,22 @@ class AmDiagGmm:
                                                float(log_sum_exp_prune), _fp(out), ldo))
         return out
 
+    def Submit(self, feats, out, log_sum_exp_prune=-1.0):
+        """Enqueues LogLikelihoods(feats) -> out without waiting (amlike_gmm_score_submit).
+        Both arrays must be float32 with unit column stride and stay alive until Wait(ticket);
+        page-locked ones (_lib.PinnedArray) make the call asynchronous."""
+        if feats.dtype != np.float32 or out.dtype != np.float32 or feats.strides[1] != 4 or out.strides[1] != 4:
+            raise ValueError("Submit needs float32 arrays with contiguous rows")
+        T, D = feats.shape
+        ticket = c_int32(-1)
+        _lib.check(_lib.lib().amlike_gmm_score_submit(self._h, _fp(feats), T, feats.strides[0] // 4, D,
+                                                      float(log_sum_exp_prune), _fp(out),
+                                                      out.strides[0] // 4, ctypes.byref(ticket)))
+        return ticket.value
+
+    def Wait(self, ticket):
+        _lib.check(_lib.lib().amlike_gmm_score_wait(self._h, int(ticket)))
+
     def LogLikelihoodsDevice(self, d_feats_ptr, T, ld, D, d_out_ptr, ldo, stream=None,
                              log_sum_exp_prune=-1.0):
         """Device-pointer form (asynchronous on `stream`)."""

@@ -105,6 +105,20 @@ class AmNnet:
                                                   mode, float(prob_scale), _fp(out), out.shape[1]))
         return out
 
+    def Submit(self, feats, out, pad_input=True, mode=POSTERIORS, prob_scale=1.0):
+        """Enqueues Compute(feats) -> out without waiting (amlike_nnet_compute_submit); both
+        arrays float32 with contiguous rows, alive until Wait(ticket)."""
+        if feats.dtype != np.float32 or out.dtype != np.float32 or feats.strides[1] != 4 or out.strides[1] != 4:
+            raise ValueError("Submit needs float32 arrays with contiguous rows")
+        ticket = c_int32(-1)
+        _lib.check(_lib.lib().amlike_nnet_compute_submit(
+            self._h, _fp(feats), feats.shape[0], feats.strides[0] // 4, 1 if pad_input else 0, mode,
+            float(prob_scale), _fp(out), out.strides[0] // 4, ctypes.byref(ticket)))
+        return ticket.value
+
+    def Wait(self, ticket):
+        _lib.check(_lib.lib().amlike_nnet_compute_wait(self._h, int(ticket)))
+
     def ComputeBatchDevice(self, d_feats_ptr, ld, utt_rows, d_out_ptr, ldo, pad_input=True,
                            mode=POSTERIORS, prob_scale=1.0, stream=None):
         rows = np.ascontiguousarray(utt_rows, np.int32)

@@ -171,3 +171,79 @@ def test_decodable_am_nnet(nnet_files):
     for (_, f), (_, l) in zip(items, got):
         want = oracle.nnet_compute(comps, priors, f, pad_input=True, mode=2, prob_scale=0.1)[:, tid2pdf[1:]]
         assert l.shape == want.shape and np.abs(l - want).max() <= TOL
+
+
+def _touched(seed, T, N, permille):
+    """The mock decoder's hashed trace: a [T x N] boolean array over (frame, tid - 1)."""
+    f = np.arange(T, dtype=np.uint64)[:, None]
+    t = np.arange(1, N + 1, dtype=np.uint64)[None, :]
+    m = np.uint64(0xFFFFFFFF)
+    h = (f * np.uint64(2654435761) + t * np.uint64(40503) + np.uint64(seed * 97)) & m
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(2246822519)) & m
+    h ^= h >> np.uint64(13)
+    return (h % np.uint64(1000)) < np.uint64(permille)
+
+
+def _check_replay(got, items, dense_of, touched_of):
+    assert [k for k, _ in got] == [k for k, _ in items]
+    for (_, f), (_, o) in zip(items, got):
+        dense = dense_of(f).astype(np.float64)          # [T x N] LogLikelihood(frame, tid)
+        mask = touched_of(dense.shape[0], dense.shape[1])
+        want_sum = (dense * mask).sum(1)
+        want_cnt = mask.sum(1)
+        assert o.shape == (dense.shape[0], 2)
+        np.testing.assert_array_equal(o[:, 1], want_cnt.astype(np.float32))
+        # per look-up tolerance TOL (scaled), summed over the look-ups of the frame
+        assert (np.abs(o[:, 0] - want_sum) <= 0.1 * TOL * np.maximum(want_cnt, 1) + 1e-3).all()
+
+
+@pytest.mark.parametrize("double_buffer", ["true", "false"])
+def test_mock_decode_gmm_hashed_trace(gmm_files, double_buffer):
+    d, model, items, tid2pdf = gmm_files
+    out = str(d / ("mock_%s.ark" % double_buffer))
+    p = run("amlike-mock-decode", "--double-buffer=" + double_buffer, "--touch=0.3", "--seed=7",
+            "--acoustic-scale=0.1", "gmm", str(d / "final.mdl"), "ark:" + str(d / "feats.ark"), "ark:" + out)
+    assert b"5 utterances" in p.stderr and ("double-buffer=" + double_buffer).encode() in p.stderr
+    _check_replay(kio.read_ark(out), items,
+                  lambda f: np.float32(0.1) * oracle_gmm(model, f)[:, tid2pdf[1:]],
+                  lambda T, N: _touched(7, T, N, 300))
+
+
+def test_mock_decode_both_orders_agree_exactly_on_a_recorded_trace(gmm_files):
+    d, model, items, tid2pdf = gmm_files
+    rng = np.random.default_rng(3)
+    N = len(tid2pdf) - 1
+    traces = []
+    for key, f in items:
+        n = 20 * f.shape[0]
+        tr = np.stack([rng.integers(0, f.shape[0], n), rng.integers(1, N + 1, n)], 1).astype(np.float32)
+        traces.append((key, tr))
+    kio.write_ark(str(d / "trace.ark"), traces)
+    outs = []
+    for db in ("true", "false"):
+        out = str(d / ("mock_tr_%s.ark" % db))
+        run("amlike-mock-decode", "--double-buffer=" + db, "--trace-rspecifier=ark:" + str(d / "trace.ark"),
+            "gmm", str(d / "final.mdl"), "ark:" + str(d / "feats.ark"), "ark:" + out)
+        outs.append(kio.read_ark(out))
+    for (ka, a), (kb, b), (_, f), (_, tr) in zip(outs[0], outs[1], items, traces):
+        assert ka == kb
+        np.testing.assert_array_equal(a, b)
+        dense = (np.float32(0.1) * oracle_gmm(model, f)[:, tid2pdf[1:]]).astype(np.float64)
+        want = np.zeros(f.shape[0])
+        np.add.at(want, tr[:, 0].astype(int), dense[tr[:, 0].astype(int), tr[:, 1].astype(int) - 1])
+        cnt = np.bincount(tr[:, 0].astype(int), minlength=f.shape[0])
+        np.testing.assert_array_equal(a[:, 1], cnt.astype(np.float32))
+        assert (np.abs(a[:, 0] - want) <= 0.1 * TOL * np.maximum(cnt, 1) + 1e-3).all()
+
+
+@pytest.mark.parametrize("double_buffer", ["true", "false"])
+def test_mock_decode_nnet(nnet_files, double_buffer):
+    d, comps, priors, items, tid2pdf = nnet_files
+    out = str(d / ("mock_%s.ark" % double_buffer))
+    run("amlike-mock-decode", "--double-buffer=" + double_buffer, "--touch=0.2", "--seed=2",
+        "--acoustic-scale=0.1", "nnet", str(d / "final.mdl"), "ark:" + str(d / "feats.ark"), "ark:" + out)
+    _check_replay(kio.read_ark(out), items,
+                  lambda f: oracle.nnet_compute(comps, priors, f, pad_input=True, mode=2,
+                                                prob_scale=0.1)[:, tid2pdf[1:]],
+                  lambda T, N: _touched(2, T, N, 200))

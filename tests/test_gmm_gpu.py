@@ -314,3 +314,59 @@ def test_many_tiny_pdfs(amlike_device, per):
     feats = synth.make_feats(m, 97, seed=301)
     am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
     _check(m, feats, am.LogLikelihoods(feats))
+
+
+def test_submit_wait_matches_the_synchronous_call(amlike_device):
+    """Two utterances in flight at a time, page-locked buffers; a third submission is refused
+    until one has been waited for; results equal amlike_gmm_score's bit for bit."""
+    m = synth.make_gmm(40, 300, 3000, seed=41)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    lens = [700, 64, 1301, 5, 999]
+    feats = [synth.make_feats(m, t, seed=50 + i) for i, t in enumerate(lens)]
+    want = [am.LogLikelihoods(f) for f in feats]
+    pin_in = [_lib.PinnedArray(max(lens), 40) for _ in range(2)]
+    pin_out = [_lib.PinnedArray(max(lens), 300) for _ in range(2)]
+    tickets = {}
+
+    def submit(i):
+        s = i % 2
+        pin_in[s].a[:lens[i]] = feats[i]
+        tickets[i] = am.Submit(pin_in[s].a[:lens[i]], pin_out[s].a[:lens[i]])
+
+    submit(0)
+    submit(1)
+    with pytest.raises(_lib.AmlikeError) as e:
+        am.Submit(feats[2], np.empty((lens[2], 300), np.float32))
+    assert e.value.code == _lib.EBUSY
+    for i in range(len(lens)):
+        am.Wait(tickets[i])
+        got = pin_out[i % 2].a[:lens[i]].copy()
+        np.testing.assert_array_equal(got, want[i])
+        if i + 2 < len(lens):
+            submit(i + 2)
+    with pytest.raises(_lib.AmlikeError):
+        am.Wait(tickets[0])  # no longer in flight
+    # ordinary (pageable) buffers work too, and a strided output
+    out = np.zeros((lens[3], 320), np.float32)
+    t = am.Submit(feats[3], out[:, :300])
+    am.Wait(t)
+    np.testing.assert_array_equal(out[:, :300], want[3])
+    assert not out[:, 300:].any()
+    for p in pin_in + pin_out:
+        p.close()
+
+
+def test_submit_reports_non_finite_answers_at_wait(amlike_device):
+    m = synth.make_gmm(13, 5, 20, seed=43)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    good = synth.make_feats(m, 30, seed=44)
+    bad = good.copy()
+    bad[7, 3] = np.nan
+    o1, o2 = np.empty((30, 5), np.float32), np.empty((30, 5), np.float32)
+    t1 = am.Submit(bad, o1)
+    t2 = am.Submit(good, o2)
+    with pytest.raises(_lib.AmlikeError) as e:
+        am.Wait(t1)
+    assert e.value.code == _lib.ENONFINITE
+    am.Wait(t2)  # the flag of the first does not leak into the second
+    np.testing.assert_array_equal(o2, am.LogLikelihoods(good))

@@ -132,3 +132,36 @@ def test_fused_affine_pnorm_matches_unfused_and_oracle(amlike_device, hidden, pn
         net.close()
         assert np.abs(outs[nofuse] - want).max() <= 1e-3
     assert np.abs(outs[""] - outs["1"]).max() <= 2e-4
+
+
+@pytest.mark.parametrize("pad", [True, False])
+def test_submit_wait_matches_the_synchronous_call(amlike_device, pad):
+    comps, priors = _nets()["mid"]
+    net = nnet.AmNnet(comps, priors)
+    rng = np.random.default_rng(77)
+    lens = [120, 33, 410, 9, 77]
+    ctx = 0 if pad else net.LeftContext() + net.RightContext()
+    utts = [rng.normal(size=(n, 40)).astype(np.float32) for n in lens]
+    want = [net.Compute(u, pad_input=pad, mode=nnet.LOGLIKES, prob_scale=0.5) for u in utts]
+    pin_in = [_lib.PinnedArray(max(lens), 40) for _ in range(2)]
+    pin_out = [_lib.PinnedArray(max(lens), net.OutputDim()) for _ in range(2)]
+    tickets = {}
+
+    def submit(i):
+        s = i % 2
+        pin_in[s].a[:lens[i]] = utts[i]
+        tickets[i] = net.Submit(pin_in[s].a[:lens[i]], pin_out[s].a[:lens[i] - ctx], pad_input=pad,
+                                mode=nnet.LOGLIKES, prob_scale=0.5)
+
+    submit(0)
+    submit(1)
+    with pytest.raises(_lib.AmlikeError) as e:
+        net.Submit(utts[2], np.empty((lens[2] - ctx, net.OutputDim()), np.float32), pad_input=pad)
+    assert e.value.code == _lib.EBUSY
+    for i in range(len(lens)):
+        net.Wait(tickets[i])
+        np.testing.assert_array_equal(pin_out[i % 2].a[:lens[i] - ctx], want[i])
+        if i + 2 < len(lens):
+            submit(i + 2)
+    for p in pin_in + pin_out:
+        p.close()
