@@ -158,6 +158,44 @@ int amlike_gmm_time_score_dev(amlike_gmm_t *gmm, const float *d_feats, int32_t T
                               int32_t feat_dim, float *d_out, int32_t ldo, void *stream,
                               int32_t iters, float *ms_per_launch);
 
+/* ---- feature front end of the GMM systems -------------------------------- */
+
+typedef struct amlike_xform amlike_xform_t;
+
+/* Replaces `splice-feats --left-context=L --right-context=R | transform-feats final.mat`
+ * (egs/wsj/s5/steps/decode.sh:84-105; SpliceFrames, feat/feature-functions.cc:391-412: frame t
+ * becomes frames t-L .. t+R side by side, edge frames repeated; featbin/transform-feats.cc:92-108:
+ * y = M x, or y = M [x; 1] when M has one column more than x has entries).
+ * mat is [rows x cols] row-major dense with cols = dim (L+R+1) or that plus one; mat == NULL:
+ * splicing only.  At most 128 rows (or spliced columns when mat is NULL). */
+int amlike_xform_create(int32_t dim, int32_t left, int32_t right, const float *mat, int32_t rows,
+                        int32_t cols, amlike_xform_t **out);
+int amlike_xform_destroy(amlike_xform_t *xf);
+int32_t amlike_xform_input_dim(const amlike_xform_t *xf);
+int32_t amlike_xform_output_dim(const amlike_xform_t *xf);
+
+/* Applies it to one utterance (host pointers, synchronous), followed -- when spk_mat is not
+ * NULL -- by a second transform-feats pass with that [rows2 x cols2] matrix, the per-speaker
+ * fMLLR step `transform-feats --utt2spk=ark:utt2spk ark:trans.JOB` of the same scripts.
+ * out is [T x (rows2, or the first stage's output dimension)] with row stride ldo. */
+int amlike_xform_apply(amlike_xform_t *xf, const float *feats, int32_t T, int32_t ld,
+                       const float *spk_mat, int32_t rows2, int32_t cols2, float *out, int32_t ldo);
+
+/* Device-pointer, asynchronous form over a batch of utterances laid back to back
+ * (utt_rows[u] frames each; edges are repeated per utterance).  d_spk_mats holds matrices of
+ * [rows2 x cols2] back to back in device memory and utt_mat[u] (host array, or NULL for
+ * "matrix 0 for all") picks utterance u's, -1 meaning none. */
+int amlike_xform_apply_dev(amlike_xform_t *xf, const float *d_in, int32_t ld,
+                           const int32_t *utt_rows, int32_t num_utts, const float *d_spk_mats,
+                           int32_t rows2, int32_t cols2, const int32_t *utt_mat, float *d_out,
+                           int32_t ldo, void *stream);
+
+/* amlike_xform_apply followed by amlike_gmm_score without the trip through host memory: the
+ * un-spliced features go up, the log-likelihoods come down (host pointers, synchronous). */
+int amlike_gmm_score_raw(amlike_gmm_t *gmm, amlike_xform_t *xf, const float *raw_feats, int32_t T,
+                         int32_t ld, const float *spk_mat, int32_t rows2, int32_t cols2,
+                         float log_sum_exp_prune, float *out, int32_t ldo);
+
 /* ---- nnet2 forward -------------------------------------------------------- */
 
 /* Component kinds of the p-norm nnet2 forward path

@@ -43,6 +43,13 @@ def _declare(lib):
         "amlike_gmm_score_wait": (ctypes.c_int, [c_void_p, c_int32]),
         "amlike_nnet_compute_submit": (ctypes.c_int, [c_void_p, fp, c_int32, c_int32, c_int32, c_int32, c_float, fp, c_int32, ip]),
         "amlike_nnet_compute_wait": (ctypes.c_int, [c_void_p, c_int32]),
+        "amlike_xform_create": (ctypes.c_int, [c_int32, c_int32, c_int32, fp, c_int32, c_int32, POINTER(c_void_p)]),
+        "amlike_xform_destroy": (ctypes.c_int, [c_void_p]),
+        "amlike_xform_input_dim": (c_int32, [c_void_p]),
+        "amlike_xform_output_dim": (c_int32, [c_void_p]),
+        "amlike_xform_apply": (ctypes.c_int, [c_void_p, fp, c_int32, c_int32, fp, c_int32, c_int32, fp, c_int32]),
+        "amlike_xform_apply_dev": (ctypes.c_int, [c_void_p, c_void_p, c_int32, ip, c_int32, c_void_p, c_int32, c_int32, ip, c_void_p, c_int32, c_void_p]),
+        "amlike_gmm_score_raw": (ctypes.c_int, [c_void_p, c_void_p, fp, c_int32, c_int32, fp, c_int32, c_int32, c_float, fp, c_int32]),
         "amlike_gmm_create": (ctypes.c_int, [fp, fp, fp, ip, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
         "amlike_gmm_destroy": (ctypes.c_int, [c_void_p]),
         "amlike_gmm_compute_gconsts": (ctypes.c_int, [fp, fp, fp, c_int32, c_int32, fp, ip]),

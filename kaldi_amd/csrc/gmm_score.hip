@@ -1231,6 +1231,7 @@ struct amlike_gmm {
   hipStream_t copy_stream = nullptr;  // submit / wait: the copies out, behind the kernels
   AsyncSlot slots[kAsyncSlots];
   int32_t next_ticket = 0;
+  DeviceBuffer ws_raw;  // un-spliced features + speaker transform of amlike_gmm_score_raw
   DeviceBuffer ws_feats, ws_out, ws_part, ws_pad, ws_expand, ws_expand_safe, ws_fix, ws_gauss;
   std::mutex mu;
   std::string info;
@@ -1834,6 +1835,7 @@ int amlike_gmm_destroy(amlike_gmm_t *g) {
   (void)hipFree(g->d_offsets);
   g->ws_gauss.Free();
   g->ws_feats.Free();
+  g->ws_raw.Free();
   g->ws_out.Free();
   g->ws_part.Free();
   g->ws_pad.Free();
@@ -1900,40 +1902,20 @@ int amlike_gmm_poll(amlike_gmm_t *g, void *stream) {
   return AMLIKE_OK;
 }
 
-int amlike_gmm_score(amlike_gmm_t *g, const float *feats, int32_t T, int32_t ld,
-                     int32_t feat_dim, float log_sum_exp_prune, float *out, int32_t ldo) {
-  int rc = CheckScoreArgs(g, T, ld, feat_dim, ldo, feats, out);
-  if (rc != AMLIKE_OK) return rc;
-  std::lock_guard<std::mutex> lock(g->mu);
-  const int ldp = (g->dim + 3) & ~3;
+// Scores device-resident features in passes of bounded output size and copies each pass
+// out; g->mu is held by the caller.
+static int ScoreResidentToHost(amlike_gmm *g, const float *df, int T, int dld, float prune,
+                               float *out, int ldo) {
   const int P = g->num_pdfs;
   // Bound the device footprint of one pass: at most ~1 GiB of output.
   const int max_t = std::max(1024, (int)std::min<size_t>(1u << 20, ((size_t)1 << 28) / (size_t)P));
   int status = AMLIKE_OK;
-  // Rows travel as one contiguous copy whenever the host layout allows it (a strided
-  // 2-D copy from pageable memory degenerates into one transfer per row); the kernels
-  // take any row stride, so the features keep the caller's ld on the device.
-  const bool feats_1d = (size_t)ld <= (size_t)2 * ldp + 8;
-  const int dld = feats_1d ? ld : ldp;
   for (int t0 = 0; t0 < T; t0 += max_t) {
     const int tn = std::min(max_t, T - t0);
-    rc = g->ws_feats.Reserve((size_t)tn * dld * sizeof(float));
+    int rc = g->ws_out.Reserve((size_t)tn * P * sizeof(float));
     if (rc != AMLIKE_OK) return rc;
-    rc = g->ws_out.Reserve((size_t)tn * P * sizeof(float));
-    if (rc != AMLIKE_OK) return rc;
-    float *df = static_cast<float *>(g->ws_feats.ptr);
     float *dout = static_cast<float *>(g->ws_out.ptr);
-    if (feats_1d) {
-      // the last row is only dim wide in the caller's buffer
-      const size_t n = (size_t)(tn - 1) * ld + g->dim;
-      AMLIKE_HIP(hipMemcpyAsync(df, feats + (size_t)t0 * ld, n * sizeof(float), hipMemcpyHostToDevice,
-                                g->stream));
-    } else {
-      AMLIKE_HIP(hipMemcpy2DAsync(df, (size_t)dld * sizeof(float), feats + (size_t)t0 * ld,
-                                  (size_t)ld * sizeof(float), (size_t)g->dim * sizeof(float), tn,
-                                  hipMemcpyHostToDevice, g->stream));
-    }
-    rc = amlike_gmm_score_dev(g, df, tn, dld, feat_dim, log_sum_exp_prune, dout, P, g->stream);
+    rc = amlike_gmm_score_dev(g, df + (size_t)t0 * dld, tn, dld, g->dim, prune, dout, P, g->stream);
     if (rc != AMLIKE_OK) return rc;
     if (ldo == P) {
       AMLIKE_HIP(hipMemcpyAsync(out + (size_t)t0 * ldo, dout, (size_t)tn * P * sizeof(float),
@@ -1948,6 +1930,65 @@ int amlike_gmm_score(amlike_gmm_t *g, const float *feats, int32_t T, int32_t ld,
     else if (rc != AMLIKE_OK) return rc;
   }
   return status;
+}
+
+int amlike_gmm_score(amlike_gmm_t *g, const float *feats, int32_t T, int32_t ld,
+                     int32_t feat_dim, float log_sum_exp_prune, float *out, int32_t ldo) {
+  int rc = CheckScoreArgs(g, T, ld, feat_dim, ldo, feats, out);
+  if (rc != AMLIKE_OK) return rc;
+  std::lock_guard<std::mutex> lock(g->mu);
+  const int ldp = (g->dim + 3) & ~3;
+  // Rows travel as one contiguous copy whenever the host layout allows it (a strided
+  // 2-D copy from pageable memory degenerates into one transfer per row); the kernels
+  // take any row stride, so the features keep the caller's ld on the device.
+  const bool feats_1d = (size_t)ld <= (size_t)2 * ldp + 8;
+  const int dld = feats_1d ? ld : ldp;
+  rc = g->ws_feats.Reserve((size_t)T * dld * sizeof(float));
+  if (rc != AMLIKE_OK) return rc;
+  float *df = static_cast<float *>(g->ws_feats.ptr);
+  if (feats_1d) {
+    // the last row is only dim wide in the caller's buffer
+    AMLIKE_HIP(hipMemcpyAsync(df, feats, ((size_t)(T - 1) * ld + g->dim) * sizeof(float),
+                              hipMemcpyHostToDevice, g->stream));
+  } else {
+    AMLIKE_HIP(hipMemcpy2DAsync(df, (size_t)dld * sizeof(float), feats, (size_t)ld * sizeof(float),
+                                (size_t)g->dim * sizeof(float), T, hipMemcpyHostToDevice, g->stream));
+  }
+  return ScoreResidentToHost(g, df, T, dld, log_sum_exp_prune, out, ldo);
+}
+
+int amlike_gmm_score_raw(amlike_gmm_t *g, amlike_xform_t *xf, const float *raw, int32_t T, int32_t ld,
+                         const float *spk_mat, int32_t rows2, int32_t cols2,
+                         float log_sum_exp_prune, float *out, int32_t ldo) {
+  if (!g || !xf || !raw || !out || T <= 0 || ld < amlike_xform_input_dim(xf) || ldo < g->num_pdfs) {
+    SetError(T <= 0 && g && xf && raw && out ? "SpliceFrames: empty input" : "amlike_gmm_score_raw: invalid argument");
+    return AMLIKE_EINVAL;
+  }
+  const int final_dim = spk_mat ? rows2 : amlike_xform_output_dim(xf);
+  if (final_dim != g->dim) {
+    SetError("Dim mismatch: data dim = %d vs. model dim = %d", final_dim, g->dim);
+    return AMLIKE_EDIM;
+  }
+  std::lock_guard<std::mutex> lock(g->mu);
+  const int ldp = (g->dim + 3) & ~3;
+  const int in_dim = amlike_xform_input_dim(xf);
+  int rc = g->ws_raw.Reserve((size_t)T * ld * sizeof(float) +
+                             (size_t)std::max(1, rows2 * cols2) * sizeof(float) + 256);
+  if (rc == AMLIKE_OK) rc = g->ws_feats.Reserve((size_t)T * ldp * sizeof(float));
+  if (rc != AMLIKE_OK) return rc;
+  float *draw = static_cast<float *>(g->ws_raw.ptr);
+  float *dspk = draw + (((size_t)T * ld + 63) & ~(size_t)63);
+  float *df = static_cast<float *>(g->ws_feats.ptr);
+  AMLIKE_HIP(hipMemcpyAsync(draw, raw, ((size_t)(T - 1) * ld + in_dim) * sizeof(float),
+                            hipMemcpyHostToDevice, g->stream));
+  if (spk_mat)
+    AMLIKE_HIP(hipMemcpyAsync(dspk, spk_mat, (size_t)rows2 * cols2 * sizeof(float),
+                              hipMemcpyHostToDevice, g->stream));
+  if (ldp != g->dim) AMLIKE_HIP(hipMemsetAsync(df, 0, (size_t)T * ldp * sizeof(float), g->stream));
+  rc = amlike_xform_apply_dev(xf, draw, ld, &T, 1, spk_mat ? dspk : nullptr, rows2, cols2, nullptr, df,
+                              ldp, g->stream);
+  if (rc != AMLIKE_OK) return rc;
+  return ScoreResidentToHost(g, df, T, ldp, log_sum_exp_prune, out, ldo);
 }
 
 int amlike_gmm_score_submit(amlike_gmm_t *g, const float *feats, int32_t T, int32_t ld,

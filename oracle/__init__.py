@@ -129,6 +129,31 @@ class NnetLayer(ctypes.Structure):
                 ("sizes", POINTER(c_int32))]
 
 
+def splice_frames(feats, left, right):
+    """SpliceFrames (feat/feature-functions.cc:391-412): frame t becomes frames t-left ..
+    t+right side by side, indices clamped to [0, T-1]."""
+    feats = np.asarray(feats, np.float32)
+    T = feats.shape[0]
+    if T == 0 or feats.shape[1] == 0:
+        raise ValueError("SpliceFrames: empty input")
+    idx = np.clip(np.arange(T)[:, None] + np.arange(-left, right + 1)[None, :], 0, T - 1)
+    return feats[idx].reshape(T, -1)
+
+
+def transform_feats(feats, trans):
+    """The body of transform-feats (featbin/transform-feats.cc:92-108): feat * trans^T, plus
+    the last column of trans as an offset when it has one column more than the features."""
+    feats = np.asarray(feats, np.float32)
+    trans = np.asarray(trans, np.float32)
+    d = feats.shape[1]
+    if trans.shape[1] == d:
+        return (feats @ trans.T).astype(np.float32)
+    if trans.shape[1] == d + 1:
+        return ((feats @ trans[:, :d].T).astype(np.float32) + trans[:, d]).astype(np.float32)
+    raise ValueError("Transform matrix has bad dimension %dx%d versus feat dim %d"
+                     % (trans.shape[0], trans.shape[1], d))
+
+
 def _declare_nnet(L):
     fp = POINTER(c_float)
     L.oracle_nnet_compute.restype = c_int

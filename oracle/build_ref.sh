@@ -39,6 +39,11 @@ for b in nnet-component nnet-nnet am-nnet nnet-precondition nnet-precondition-on
   srcs+=("$REF/src/nnet2/$b.cc")
 done
 
+# SpliceFrames (front end of the GMM systems) and the one function of feat/ it links against
+for b in feature-functions mel-computations; do
+  srcs+=("$REF/src/feat/$b.cc")
+done
+
 compile_one() {
   f="$1"; o="$OUT/obj/$(basename "$(dirname "$f")")_$(basename "${f%.cc}").o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ]; then g++ $CXXFLAGS -c "$f" -o "$o"; fi

@@ -12,6 +12,8 @@
 //   gmm-gconsts     gmm/diag-gmm.cc:114-152            (gconsts as recomputed by Read)
 //   nnet-compute    nnet2/nnet-compute.cc:62-106 + nnet2bin/nnet-am-compute.cc:82-96
 //   nnet-loglikes   nnet2/decodable-am-nnet.h:57-69
+//   splice-transform featbin/splice-feats.cc (SpliceFrames, feat/feature-functions.cc:391-412)
+//                   then featbin/transform-feats.cc:81-108 once or twice (LDA/MLLT, then fMLLR)
 //   *-copy          Read then Write with the reference's own IO (pins the file formats)
 //
 // Model files given to this driver hold ONLY the AmDiagGmm / AmNnet object (no
@@ -26,6 +28,7 @@
 #include "util/common-utils.h"
 #include "gmm/am-diag-gmm.h"
 #include "nnet2/am-nnet.h"
+#include "feat/feature-functions.h"
 
 using namespace kaldi;
 
@@ -198,6 +201,43 @@ int main(int argc, char *argv[]) {
       SequentialBaseFloatMatrixReader reader(argv[2]);
       CompressedMatrixWriter writer(argv[3]);
       for (; !reader.Done(); reader.Next()) writer.Write(reader.Key(), CompressedMatrix(reader.Value()));
+      return 0;
+    } else if (cmd == "splice-transform") {
+      // ref_driver splice-transform <feats-rspecifier> <left> <right> <out-wspecifier> [mat1 [mat2]]
+      SequentialBaseFloatMatrixReader reader(argv[2]);
+      const int32 left = atoi(argv[3]), right = atoi(argv[4]);
+      BaseFloatMatrixWriter writer(argv[5]);
+      std::vector<Matrix<BaseFloat> > mats;
+      for (int a = 6; a < argc; a++) {
+        Matrix<BaseFloat> m;
+        ReadKaldiObject(argv[a], &m);
+        mats.push_back(m);
+      }
+      for (; !reader.Done(); reader.Next()) {
+        Matrix<BaseFloat> feat;
+        SpliceFrames(reader.Value(), left, right, &feat);
+        for (size_t i = 0; i < mats.size(); i++) {
+          // the body of transform-feats.cc:92-108
+          const Matrix<BaseFloat> &trans = mats[i];
+          int32 transform_rows = trans.NumRows(), transform_cols = trans.NumCols(),
+                feat_dim = feat.NumCols();
+          Matrix<BaseFloat> feat_out(feat.NumRows(), transform_rows);
+          if (transform_cols == feat_dim) {
+            feat_out.AddMatMat(1.0, feat, kNoTrans, trans, kTrans, 0.0);
+          } else if (transform_cols == feat_dim + 1) {
+            SubMatrix<BaseFloat> linear_part(trans, 0, transform_rows, 0, feat_dim);
+            feat_out.AddMatMat(1.0, feat, kNoTrans, linear_part, kTrans, 0.0);
+            Vector<BaseFloat> offset(transform_rows);
+            offset.CopyColFromMat(trans, feat_dim);
+            feat_out.AddVecToRows(1.0, offset);
+          } else {
+            KALDI_ERR << "Transform matrix has bad dimension " << transform_rows << "x"
+                      << transform_cols << " versus feat dim " << feat_dim;
+          }
+          feat.Swap(&feat_out);
+        }
+        writer.Write(reader.Key(), feat);
+      }
       return 0;
     } else if (cmd == "copy-feats") {
       SequentialBaseFloatMatrixReader reader(argv[2]);

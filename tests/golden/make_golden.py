@@ -16,6 +16,8 @@ Files written (all small):
   nnet_b.mdl nnet_b_feats.ark nnet_b_post.ark  sigmoid / tanh / relu / mix-up sum-group network
   cm_feats.ark  cm_feats_expanded.ark          CompressedMatrix archive and its expansion
   gsel.mdl gsel_feats.ark gsel_top5.txt        DiagGmm::GaussianSelection, 5 of 64 per frame
+  xf_feats.ark xf_mats.ark                     13-dim features; "lda" 40x92, "lin" 40x91, "fmllr" 40x41
+  xf_splice.ark xf_lda.ark xf_lin.ark xf_lda_fmllr.ark   SpliceFrames(3,3) and transform-feats once / twice
 """
 import os
 import sys
@@ -119,6 +121,27 @@ def main():
     kio.write_ark(path("gsel_feats.ark"), [("g", synth.make_feats(ubm, 60, seed=4021))])
     oracle.ref_driver("gmm-gselect", path("gsel.mdl"), "0", "5", "ark:" + path("gsel_feats.ark"),
                       path("gsel_top5.txt"))
+    # The GMM systems' front end: SpliceFrames +-3, then transform-feats with an affine
+    # (LDA+MLLT-like) matrix, a linear one, and a second per-speaker (fMLLR-like) affine one.
+    xrng = np.random.default_rng(4030)
+    xf_items = [("x%d" % i, xrng.standard_normal((n, 13)).astype(np.float32) * 3)
+                for i, n in enumerate([1, 5, 60, 131])]
+    kio.write_ark(path("xf_feats.ark"), xf_items)
+    lda = (xrng.standard_normal((40, 92)) / np.sqrt(91)).astype(np.float32)
+    lin = lda[:, :91].copy()
+    fmllr = (np.eye(40, 41) + 0.1 * xrng.standard_normal((40, 41))).astype(np.float32)
+    kio.write_ark(path("xf_mats.ark"), [("lda", lda), ("lin", lin), ("fmllr", fmllr)])
+    for name, m in (("lda", lda), ("lin", lin), ("fmllr", fmllr)):
+        with kio.open_out(path("tmp_%s.mat" % name), True) as f:
+            kio.write_matrix(f, True, m)
+    src = "ark:" + path("xf_feats.ark")
+    oracle.ref_driver("splice-transform", src, "3", "3", "ark:" + path("xf_splice.ark"))
+    oracle.ref_driver("splice-transform", src, "3", "3", "ark:" + path("xf_lda.ark"), path("tmp_lda.mat"))
+    oracle.ref_driver("splice-transform", src, "3", "3", "ark:" + path("xf_lin.ark"), path("tmp_lin.mat"))
+    oracle.ref_driver("splice-transform", src, "3", "3", "ark:" + path("xf_lda_fmllr.ark"),
+                      path("tmp_lda.mat"), path("tmp_fmllr.mat"))
+    for name in ("lda", "lin", "fmllr"):
+        os.remove(path("tmp_%s.mat" % name))
     # Compressed feature matrices as the reference writes them: "CM" (per-column percentiles +
     # bytes) for the 50- and 40-row matrices, "CM2" (16-bit) for the 7-row one; and what the
     # reference's Matrix<float>::Read makes of them.

@@ -204,3 +204,22 @@ def test_gaussian_selection_vs_golden():
                 np.abs(np.sort(scores[t])[-6] - np.sort(scores[t])[-5]) < 1e-4
         assert len(differ) <= 1
         assert abs(total - tot[key]) <= 1e-3 * len(feats)
+
+
+def test_front_end_restatement_matches_the_reference():
+    """splice_frames / transform_feats against SpliceFrames and the body of transform-feats run
+    from the real library (tests/golden/xf_*.ark)."""
+    from golden_util import load_ark
+    items = load_ark("xf_feats.ark")
+    mats = dict(load_ark("xf_mats.ark"))
+    for (k, x), (_, sp), (_, lda), (_, lin), (_, both) in zip(
+            items, load_ark("xf_splice.ark"), load_ark("xf_lda.ark"), load_ark("xf_lin.ark"),
+            load_ark("xf_lda_fmllr.ark")):
+        s = oracle.splice_frames(x, 3, 3)
+        np.testing.assert_array_equal(s, sp)
+        a = oracle.transform_feats(s, mats["lda"])
+        assert np.abs(a - lda).max() <= 1e-5
+        assert np.abs(oracle.transform_feats(s, mats["lin"]) - lin).max() <= 1e-5
+        assert np.abs(oracle.transform_feats(a, mats["fmllr"]) - both).max() <= 2e-5
+    with pytest.raises(ValueError):
+        oracle.transform_feats(np.zeros((3, 5), np.float32), np.zeros((4, 7), np.float32))
