@@ -150,6 +150,14 @@ int amlike_gmm_gselect(amlike_gmm_t *gmm, int32_t pdf, const float *feats, int32
 /* Name and grid of the kernels the last score launch used (for profiling output). */
 const char *amlike_gmm_kernel_info(const amlike_gmm_t *gmm);
 
+/* Profiling hook (CuDevice::AccuProfile analogue, cudamatrix/cu-device.h:84-92): while enabled,
+ * every score launch records a HIP event before and after its scoring kernel, on the stream
+ * the kernel is launched on (at most 256 launches between two reads).
+ * amlike_gmm_kernel_time waits for them and returns their mean duration in milliseconds and
+ * their number, then starts over. */
+int amlike_gmm_profile_kernel(amlike_gmm_t *gmm, int32_t enable);
+int amlike_gmm_kernel_time(amlike_gmm_t *gmm, float *mean_ms, int32_t *launches);
+
 /* Timing hook: runs `iters` back-to-back launches of the scoring kernel on
  * `stream`, bracketed by hipEvents on that stream, and returns the mean kernel
  * time in milliseconds in *ms_per_launch (CuDevice::AccuProfile analogue,

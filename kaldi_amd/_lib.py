@@ -63,6 +63,8 @@ def _declare(lib):
         "amlike_gmm_gauss_loglikes_dev": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
         "amlike_gmm_gselect": (ctypes.c_int, [c_void_p, c_int32, fp, c_int32, c_int32, c_int32, c_int32, ip, POINTER(ctypes.c_double)]),
         "amlike_gmm_kernel_info": (c_char_p, [c_void_p]),
+        "amlike_gmm_profile_kernel": (ctypes.c_int, [c_void_p, c_int32]),
+        "amlike_gmm_kernel_time": (ctypes.c_int, [c_void_p, POINTER(c_float), ip]),
         "amlike_gmm_time_score_dev": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, POINTER(c_float)]),
         "amlike_nnet_create": (ctypes.c_int, [POINTER(Component), c_int32, fp, c_int32, POINTER(c_void_p)]),
         "amlike_nnet_destroy": (ctypes.c_int, [c_void_p]),

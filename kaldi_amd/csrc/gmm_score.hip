@@ -1231,6 +1231,9 @@ struct amlike_gmm {
   hipStream_t copy_stream = nullptr;  // submit / wait: the copies out, behind the kernels
   AsyncSlot slots[kAsyncSlots];
   int32_t next_ticket = 0;
+  bool profile = false;  // amlike_gmm_profile_kernel: event pairs around the scoring kernel
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+  size_t kev_used = 0;
   DeviceBuffer ws_raw;  // un-spliced features + speaker transform of amlike_gmm_score_raw
   DeviceBuffer ws_feats, ws_out, ws_part, ws_pad, ws_expand, ws_expand_safe, ws_fix, ws_gauss;
   std::mutex mu;
@@ -1667,8 +1670,13 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
     GmmPackView pk{apack, gcp, g->d_endmask, g->d_segcol, g->num_wc};
+    // profiling: one event pair around the scoring kernel of the main pass, on its stream
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    if (g->profile && guard != 2 && g->kev_used < g->kev.size()) ev = &g->kev[g->kev_used++];
+    if (ev) AMLIKE_HIP(hipEventRecord(ev->first, stream));
     hipLaunchKernelGGL(kernel, dim3(nbx * nby), dim3(64 * v.W), smem, stream, pk, a);
     AMLIKE_HIP(hipGetLastError());
+    if (ev) AMLIKE_HIP(hipEventRecord(ev->second, stream));
     if (g->num_splits > 0 && v.mode < 100) {
       hipLaunchKernelGGL(gmm_merge_parts_kernel, dim3((T + 255) / 256, g->num_splits), dim3(256), 0,
                          stream, g->d_splits, g->num_splits, a.part_m, a.part_s, a.part_ld, T, d_out,
@@ -1841,6 +1849,10 @@ int amlike_gmm_destroy(amlike_gmm_t *g) {
   g->ws_pad.Free();
   g->ws_expand.Free();
   for (AsyncSlot &s : g->slots) s.Release();
+  for (auto &e : g->kev) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
   if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
   if (g->stream) (void)hipStreamDestroy(g->stream);
   delete g;
@@ -2199,6 +2211,38 @@ int amlike_gmm_gselect(amlike_gmm_t *g, int32_t pdf, const float *feats, int32_t
     for (int t = 0; t < tn; ++t) total += ll[t];
   }
   if (tot_loglike) *tot_loglike = total;
+  return AMLIKE_OK;
+}
+
+int amlike_gmm_profile_kernel(amlike_gmm_t *g, int32_t enable) {
+  if (!g) return AMLIKE_EINVAL;
+  std::lock_guard<std::mutex> lock(g->mu);
+  if (enable && g->kev.empty()) {
+    g->kev.resize(256);
+    for (auto &e : g->kev) {
+      e.first = e.second = nullptr;
+      AMLIKE_HIP(hipEventCreate(&e.first));
+      AMLIKE_HIP(hipEventCreate(&e.second));
+    }
+  }
+  g->profile = enable != 0;
+  g->kev_used = 0;
+  return AMLIKE_OK;
+}
+
+int amlike_gmm_kernel_time(amlike_gmm_t *g, float *mean_ms, int32_t *launches) {
+  if (!g || !mean_ms) return AMLIKE_EINVAL;
+  std::lock_guard<std::mutex> lock(g->mu);
+  double sum = 0.0;
+  for (size_t i = 0; i < g->kev_used; ++i) {
+    AMLIKE_HIP(hipEventSynchronize(g->kev[i].second));
+    float ms = 0.0f;
+    AMLIKE_HIP(hipEventElapsedTime(&ms, g->kev[i].first, g->kev[i].second));
+    sum += ms;
+  }
+  *mean_ms = g->kev_used ? (float)(sum / g->kev_used) : 0.0f;
+  if (launches) *launches = (int32_t)g->kev_used;
+  g->kev_used = 0;
   return AMLIKE_OK;
 }
 

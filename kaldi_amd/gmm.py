@@ -121,6 +121,16 @@ class AmDiagGmm:
     def Poll(self, stream=None):
         _lib.check(_lib.lib().amlike_gmm_poll(self._h, c_void_p(stream or 0)))
 
+    def ProfileKernel(self, enable=True):
+        """Event pairs around the scoring kernel of every launch from now on."""
+        _lib.check(_lib.lib().amlike_gmm_profile_kernel(self._h, 1 if enable else 0))
+
+    def KernelTime(self):
+        """(mean milliseconds, launches) of the scoring kernel since the last call."""
+        ms, n = c_float(0), c_int32(0)
+        _lib.check(_lib.lib().amlike_gmm_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
     def TimeScoreDevice(self, d_feats_ptr, T, ld, D, d_out_ptr, ldo, iters, stream=None):
         ms = c_float(0)
         _lib.check(_lib.lib().amlike_gmm_time_score_dev(self._h, c_void_p(d_feats_ptr), T, ld, D,
