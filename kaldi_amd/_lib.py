@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libamlike.so")
+# AMLIKE_LIB_PATH: another build of the same library (tuning aid for A/B runs)
+LIB_PATH = os.environ.get("AMLIKE_LIB_PATH") or os.path.join(_HERE, "csrc", "libamlike.so")
 
 OK, EINVAL, EDIM, ENONFINITE, EHIP, EOOM, ENODEV, EBUSY = range(8)
 

@@ -726,6 +726,12 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #ifndef AMLIKE_DIFF_PRE
 #define AMLIKE_DIFF_PRE 2
 #endif
+  // AMLIKE_DIFF_PRIO 1: a wave in its register pass (the part that feeds the matrix pipe) gets
+  // issue priority over a wave in its segment loop (-3 % on the swbd shape); 2: priority
+  // around every matrix instruction (-2 %); 0: none.
+#ifndef AMLIKE_DIFF_PRIO
+#define AMLIKE_DIFF_PRIO 1
+#endif
   // Feature fragments are requested from LDS kPre k-steps before the matrix instructions
   // that read them (a wave that waits on LDS issues nothing, its matrix work included).
   constexpr int kPre = AMLIKE_DIFF_PRE < KS ? AMLIKE_DIFF_PRE : (KS > 1 ? KS - 1 : 1);
@@ -750,12 +756,18 @@ __global__ void __launch_bounds__(64 * W, OCC)
       pb = (which == 0 || which == 3 || which == 5) ? 0 : (which == 1 || which == 4) ? 1 : 2;
     }
     const f32x16 c = (s == 0 && which == 0) ? gcv[nt] : acc[nt];
+#if AMLIKE_DIFF_PRIO == 2
+    __builtin_amdgcn_s_setprio(2);
+#endif
     if (PREC)
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[nt][s][pa]),
                                                        __builtin_bit_cast(f16x8, bf[s % NB][pb]),
                                                        c, 0, 0, 0);
     else
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][s][pa], bf[s % NB][pb], c, 0, 0, 0);
+#if AMLIKE_DIFF_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   auto load_b_head = [&](const uint4 *bt) {
 #pragma unroll
@@ -779,6 +791,12 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #pragma unroll
   for (int n = 0; n < kMfma; ++n) mfma_n(acc_cur, s_b + lane, n);
 
+  // The 0/1 factors of the running sums, one per accumulator register, fixed for the life
+  // of the wave and held in scalar registers.
+  float keepf[kSteps];
+#pragma unroll
+  for (int st = 0; st < kSteps; ++st) keepf[st] = scalar_bit_as_float(keepm, st);
+
   for (int ft = 0; ft < ntile; ++ft) {
     const int t0 = t_begin + (ft << 5);
     const int row = t0 + j;
@@ -798,6 +816,9 @@ __global__ void __launch_bounds__(64 * W, OCC)
     // the running sums of tile ft.
     svec sv;
     float s_ = 0.0f;
+#if AMLIKE_DIFF_PRIO == 1
+    __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
     for (int st = 0; st < kSteps; ++st) {
       const int nt = st >> 4, i = st & 15;
@@ -812,13 +833,16 @@ __global__ void __launch_bounds__(64 * W, OCC)
       if (ABL & 2) {
         asm volatile("" ::"v"(acc_cur[nt][i]));
       } else {
-        const float keep = scalar_bit_as_float(keepm, st);  // does the sum continue into this register?
-        s_ = fmaf(s_, keep, fast_exp2(acc_cur[nt][i]));
+        // keepf[st]: does the sum continue into this register?
+        s_ = fmaf(s_, keepf[st], fast_exp2(acc_cur[nt][i]));
         pin_order(s_);
       }
       sv[st] = s_;
     }
 
+#if AMLIKE_DIFF_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // Loop over the segments of this wave's chunk, two per iteration: lanes 0-31 finish
     // segment 2k and lanes 32-63 segment 2k+1 of the same 32 frames.  One
     // v_permlane32_swap of (value for a, value for b) leaves, in each half-wave, that
@@ -852,8 +876,14 @@ __global__ void __launch_bounds__(64 * W, OCC)
         if (row < t_end) {
           if (col >= 0) {
             float v = (ref + fast_log2(S)) * kLn2;
-            if (!(ABL & 1)) orow[col] = v;
-            else pin_order(v);
+            if (ABL & 32) {
+              // timing experiment: the same number of store instructions, but 64 consecutive floats
+              ar.out[(size_t)min(t0 + (col & 31), ar.T - 2) * ar.ldo + (col & ~31) + lane] = v;
+            } else if (!(ABL & 1)) {
+              orow[col] = v;
+            } else {
+              pin_order(v);
+            }
             if (!ABL && !(fabsf(v) <= kMaxAbsLogLike)) {
               const int kk = atomicAdd(ar.ctl, 1);
               if (kk < ar.fix_cap) ar.fix_list[kk] = make_int2(row, col);
@@ -1192,6 +1222,7 @@ static const Variant kVariants[] = {
     AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 2), AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 4),
     AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 6), AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 14),
     AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 30), AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 8),
+    AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 32),
 #endif
     AMLIKE_VARIANT(40, 3, 8), AMLIKE_VARIANT(39, 3, 8),
     AMLIKE_VARIANT(40, 6, 4), AMLIKE_VARIANT(39, 6, 4),
