@@ -1,6 +1,8 @@
 // Host-side nnet2 model classes (see nnet_model.h).
 #include "nnet_model.h"
 
+#include <algorithm>
+
 namespace kaldi_amd {
 namespace nnet2 {
 
@@ -263,5 +265,81 @@ DecodableAmNnet::DecodableAmNnet(const TransitionModel &trans_model, const AmNne
   NnetComputation(am_nnet, feats, pad_input, AMLIKE_NNET_LOGLIKES, prob_scale, &log_probs_);
 }
 
+// nnet2/online-nnet2-decodable.cc:25-45.
+DecodableNnet2Online::DecodableNnet2Online(const AmNnet &nnet, const TransitionModel &trans_model,
+                                           const DecodableNnet2OnlineOptions &opts,
+                                           OnlineFeatureInterface *input_feats)
+    : features_(input_feats), nnet_(nnet), trans_model_(trans_model), opts_(opts),
+      feat_dim_(input_feats->Dim()), left_context_(nnet.GetNnet().LeftContext()),
+      right_context_(nnet.GetNnet().RightContext()), num_pdfs_(nnet.GetNnet().OutputDim()) {
+  if (opts_.max_nnet_batch_size <= 0) KaldiErr("DecodableNnet2Online: max_nnet_batch_size must be positive");
+  if (nnet.Priors().Dim() != trans_model.NumPdfs())
+    KaldiErr("Priors in neural network not set up (or mismatch with transition model).");
+  if (feat_dim_ != nnet.GetNnet().InputDim())
+    KALDI_AMD_ERR("Feature dimension is " << feat_dim_ << " but network expects "
+                  << nnet.GetNnet().InputDim());
+}
+
+// :49-55
+BaseFloat DecodableNnet2Online::LogLikelihood(int32 frame, int32 index) {
+  ComputeForFrame(frame);
+  const int32 pdf_id = trans_model_.TransitionIdToPdf(index);
+  return scaled_loglikes_(frame - begin_frame_, pdf_id);
+}
+
+// :58-64
+bool DecodableNnet2Online::IsLastFrame(int32 frame) const {
+  if (opts_.pad_input) return features_->IsLastFrame(frame);
+  return features_->IsLastFrame(frame + left_context_ + right_context_);
+}
+
+// :66-80
+int32 DecodableNnet2Online::NumFramesReady() const {
+  const int32 features_ready = features_->NumFramesReady();
+  if (features_ready == 0) return 0;
+  const bool input_finished = features_->IsLastFrame(features_ready - 1);
+  if (opts_.pad_input) {
+    if (input_finished) return features_ready;
+    return std::max<int32>(0, features_ready - right_context_);
+  }
+  return std::max<int32>(0, features_ready - right_context_ - left_context_);
+}
+
+// :82-142.  The batch of input frames is gathered on the host exactly as the reference does
+// (edge frames repeated when pad_input), then one GPU call computes the network on it with
+// no further padding and applies floor, log, minus log-prior and the acoustic scale.
+void DecodableNnet2Online::ComputeForFrame(int32 frame) {
+  const int32 features_ready = features_->NumFramesReady();
+  const bool input_finished = features_->IsLastFrame(features_ready - 1);
+  if (frame < 0) KaldiErr("DecodableNnet2Online: negative frame");
+  if (frame >= begin_frame_ && frame < begin_frame_ + scaled_loglikes_.NumRows()) return;
+  if (frame >= NumFramesReady()) KALDI_AMD_ERR("DecodableNnet2Online: frame " << frame << " is not ready");
+  const int32 input_frame_begin = opts_.pad_input ? frame - left_context_ : frame;
+  int32 max_possible_input_frame_end = features_ready;
+  if (input_finished && opts_.pad_input) max_possible_input_frame_end += right_context_;
+  const int32 input_frame_end =
+      std::min<int32>(max_possible_input_frame_end,
+                      input_frame_begin + left_context_ + right_context_ + opts_.max_nnet_batch_size);
+  Matrix features(input_frame_end - input_frame_begin, feat_dim_);
+  Vector row(feat_dim_);
+  for (int32 t = input_frame_begin; t < input_frame_end; t++) {
+    int32 t_modified = t;
+    if (t_modified < 0) t_modified = 0;
+    if (t_modified >= features_ready) t_modified = features_ready - 1;
+    features_->GetFrame(t_modified, &row);
+    std::copy(row.Data(), row.Data() + feat_dim_, features.RowData(t - input_frame_begin));
+  }
+  NnetComputation(nnet_, features, false, AMLIKE_NNET_LOGLIKES, opts_.acoustic_scale, &scaled_loglikes_);
+  begin_frame_ = frame;
+  ++num_batches_;
+}
+
 }  // namespace nnet2
+
+void OnlineMatrixFeature::GetFrame(int32 frame, Vector *feat) {
+  if (frame < 0 || frame >= ready_) KALDI_AMD_ERR("OnlineMatrixFeature: frame " << frame << " has not arrived");
+  feat->Resize(mat_.NumCols());
+  std::copy(mat_.RowData(frame), mat_.RowData(frame) + mat_.NumCols(), feat->Data());
+}
+
 }  // namespace kaldi_amd

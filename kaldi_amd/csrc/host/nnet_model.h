@@ -89,6 +89,67 @@ class DecodableAmNnet : public DecodableInterface {
 };
 
 }  // namespace nnet2
+
+// itf/online-feature-itf.h:48-80.
+class OnlineFeatureInterface {
+ public:
+  virtual int32 Dim() const = 0;
+  virtual int32 NumFramesReady() const = 0;
+  virtual bool IsLastFrame(int32 frame) const = 0;
+  virtual void GetFrame(int32 frame, Vector *feat) = 0;
+  virtual ~OnlineFeatureInterface() {}
+};
+
+// feat/online-feature.h:114-135, plus a knob for tests and simulations: only the first
+// `ready` rows count as arrived until SetFramesReady() raises the number.
+class OnlineMatrixFeature : public OnlineFeatureInterface {
+ public:
+  explicit OnlineMatrixFeature(const Matrix &mat) : mat_(mat), ready_(mat.NumRows()) {}
+  void SetFramesReady(int32 ready) { ready_ = ready < mat_.NumRows() ? ready : mat_.NumRows(); }
+  int32 Dim() const override { return mat_.NumCols(); }
+  int32 NumFramesReady() const override { return ready_; }
+  bool IsLastFrame(int32 frame) const override { return frame + 1 == mat_.NumRows(); }
+  void GetFrame(int32 frame, Vector *feat) override;
+
+ private:
+  const Matrix &mat_;
+  int32 ready_;
+};
+
+namespace nnet2 {
+
+// nnet2/online-nnet2-decodable.h:31-55.
+struct DecodableNnet2OnlineOptions {
+  BaseFloat acoustic_scale = 0.1f;
+  bool pad_input = true;
+  int32 max_nnet_batch_size = 256;
+};
+
+// nnet2/online-nnet2-decodable.{h,cc}: log-likelihoods computed in batches as the decoder
+// reaches frames that have not been computed yet, from whatever input has arrived.
+class DecodableNnet2Online : public DecodableInterface {
+ public:
+  DecodableNnet2Online(const AmNnet &nnet, const TransitionModel &trans_model,
+                       const DecodableNnet2OnlineOptions &opts, OnlineFeatureInterface *input_feats);
+  BaseFloat LogLikelihood(int32 frame, int32 index) override;
+  bool IsLastFrame(int32 frame) const override;
+  int32 NumFramesReady() const override;
+  int32 NumIndices() const override { return trans_model_.NumTransitionIds(); }
+  int32 NumBatchesComputed() const { return num_batches_; }
+
+ private:
+  void ComputeForFrame(int32 frame);
+  OnlineFeatureInterface *features_;
+  const AmNnet &nnet_;
+  const TransitionModel &trans_model_;
+  DecodableNnet2OnlineOptions opts_;
+  int32 feat_dim_, left_context_, right_context_, num_pdfs_;
+  int32 begin_frame_ = -1;
+  int32 num_batches_ = 0;
+  Matrix scaled_loglikes_;
+};
+
+}  // namespace nnet2
 }  // namespace kaldi_amd
 
 #endif  // KALDI_AMD_CSRC_HOST_NNET_MODEL_H_

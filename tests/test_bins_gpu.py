@@ -247,3 +247,28 @@ def test_mock_decode_nnet(nnet_files, double_buffer):
                   lambda f: oracle.nnet_compute(comps, priors, f, pad_input=True, mode=2,
                                                 prob_scale=0.1)[:, tid2pdf[1:]],
                   lambda T, N: _touched(2, T, N, 200))
+
+
+@pytest.mark.parametrize("pad,chunk,batch", [(True, 50, 256), (True, 7, 16), (False, 33, 40), (True, 1000, 64)])
+def test_decodable_nnet2_online_equals_whole_utterance_scoring(nnet_files, pad, chunk, batch):
+    """DecodableNnet2Online (batches computed as frames arrive) gives the same log-likelihoods
+    as the whole-utterance computation; the reference semantics of NumFramesReady / IsLastFrame
+    decide how many frames come out."""
+    d, comps, priors, items, tid2pdf = nnet_files
+    out = str(d / ("online_%d_%d_%d.ark" % (pad, chunk, batch)))
+    p = run("amlike-decodable", "--acoustic-scale=0.1", "--pad-input=%s" % str(pad).lower(),
+            "--arrival-chunk=%d" % chunk, "--max-nnet-batch-size=%d" % batch, "nnet-online",
+            str(d / "final.mdl"), "ark:" + str(d / "feats.ark"), "ark:" + out)
+    got = dict(kio.read_ark(out))
+    for key, f in items:
+        l = got[key]
+        if not pad and f.shape[0] <= 8:
+            assert l.shape[0] == 0
+            continue
+        want = oracle.nnet_compute(comps, priors, f, pad_input=pad, mode=2, prob_scale=0.1)[:, tid2pdf[1:]]
+        assert l.shape == want.shape
+        assert np.abs(l - want).max() <= TOL
+    if batch == 16:  # 300 frames cannot have been one batch
+        assert b"u2: 300 frames in" in p.stderr
+        n = int(p.stderr.split(b"u2: 300 frames in ")[1].split()[0])
+        assert n >= 300 // 16
