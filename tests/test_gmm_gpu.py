@@ -370,3 +370,43 @@ def test_submit_reports_non_finite_answers_at_wait(amlike_device):
     assert e.value.code == _lib.ENONFINITE
     am.Wait(t2)  # the flag of the first does not leak into the second
     np.testing.assert_array_equal(o2, am.LogLikelihoods(good))
+
+
+def test_swbd_tri4_full_size(amlike_device, monkeypatch):
+    """The benchmark's model at its full size (D=40, 8600 pdfs, 200 000 Gaussians): the oracle
+    on a sample of frames, and properties that need no oracle on all of them -- the exact-fp32
+    kernel family as an independent second opinion, frames scored alone or in any batch and
+    order giving the same bits, and the bounds max_m f_m <= LSE <= max_m f_m + log M."""
+    D, P, G = synth.GMM_CONFIGS["swbd_tri4"]
+    m = synth.make_gmm(D, P, G, seed=777)
+    T = 4100
+    feats = synth.make_feats(m, T, seed=778)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    got = am.LogLikelihoods(feats)
+    assert "gmm_score_diff_kernel" in am.kernel_info() and "f16x2" in am.kernel_info()
+    assert np.isfinite(got).all()
+    # (a) oracle on 48 frames spread over the batch
+    rows = np.linspace(0, T - 1, 48).astype(int)
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    want, st = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"], feats[rows])
+    assert st == 0
+    assert np.abs(got[rows] - want).max() <= TOL
+    assert (got[rows].argmax(1) == want.argmax(1)).all()
+    # (b) batch composition and order do not change a frame's scores
+    perm = np.random.default_rng(5).permutation(T)
+    np.testing.assert_array_equal(am.LogLikelihoods(feats[perm]), got[perm])
+    np.testing.assert_array_equal(am.LogLikelihoods(feats[1000:1037]), got[1000:1037])
+    # (c) bounds from the per-Gaussian scores of a few pdfs
+    for j in (0, 4321, P - 1):
+        comp = am.ComponentLogLikelihoods(feats[:512], j, j + 1)
+        mx = comp.max(1)
+        assert (got[:512, j] >= mx - 1e-3).all()
+        assert (got[:512, j] <= mx + np.log(comp.shape[1]) + 1e-3).all()
+    am.close()
+    # (d) the exact-fp32 kernel family on all frames
+    monkeypatch.setenv("AMLIKE_GMM_MODE", "f32")
+    am32 = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    ref = am32.LogLikelihoods(feats)
+    assert "gmm_score_kernel" in am32.kernel_info()
+    assert np.abs(ref - got).max() <= TOL
+    assert (ref.argmax(1) == got.argmax(1)).mean() >= 0.9999

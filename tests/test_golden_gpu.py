@@ -11,12 +11,15 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("tag", ["gmm_a", "gmm_b"])
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("mode", ["default", "diff-f16x2", "diff-bf16x3", "bf16x3", "f32"])
 def test_gmm_likes_vs_golden(amlike_device, tag, mode, monkeypatch):
     m = load_am_gmm(tag + ".mdl")
     if mode == "f32" and m["dim"] not in (39, 40):
         pytest.skip("the exact-fp32 kernel is built for dims 39 and 40")
-    monkeypatch.setenv("AMLIKE_GMM_MODE", mode)
+    if mode == "default":
+        monkeypatch.delenv("AMLIKE_GMM_MODE", raising=False)
+    else:
+        monkeypatch.setenv("AMLIKE_GMM_MODE", mode)
     am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
     want = dict(load_ark(tag + "_likes.ark"))
     for key, feats in load_ark(tag + "_feats.ark"):
@@ -24,6 +27,8 @@ def test_gmm_likes_vs_golden(amlike_device, tag, mode, monkeypatch):
         assert got.shape == want[key].shape
         assert np.abs(got - want[key]).max() <= 1e-3
         assert (got.argmax(1) == want[key].argmax(1)).all()
+    if mode == "default":
+        assert "gmm_score_diff_kernel" in am.kernel_info()
 
 
 def test_gmm_gconsts_vs_golden_bits(amlike_device):
