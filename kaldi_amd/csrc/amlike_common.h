@@ -43,6 +43,14 @@ struct AsyncSlot {
 };
 constexpr int kAsyncSlots = 2;
 
+// Y[M x N] = X W^T + bias on the bf16x3 matrix-instruction GEMM of the nnet2 path
+// (nnet_forward.hip).  Operands are three bf16 planes (x = p1 + p2 + p3 exactly) of 16-byte
+// elements holding 8 consecutive k of one row, k-octet-major: element (plane q, octet o, row r)
+// of X sits at q * xplane + o * M + r; of W at q * wplane + o * woct + r, so that W may be a
+// row range of a larger image.  Kp = padded k, a multiple of 16.
+int LaunchPlaneGemmBf16x3(const void *xp, size_t xplane, const void *wp, size_t wplane, size_t woct,
+                          int Kp, const float *bias, float *y, int ldy, int M, int N, hipStream_t st);
+
 // fp32 -> bf16, round to nearest even (inf / nan: truncated).
 static inline uint16_t Bf16Rne(float x) {
   uint32_t u;

@@ -1002,6 +1002,50 @@ __global__ void gmm_pad_feats_kernel(const float *src, int T, int ld, int dim, f
   }
 }
 
+// The operands of the per-Gaussian score GEMM as bf16x3 planes (value = p1 + p2 + p3
+// exactly), 8 consecutive k of one row per 16-byte element, k-octet-major: element
+// (plane q, octet o, row r) at q * pstride + o * rows + r.  Row r of the k axis is
+//   MODEL = false (features): [x_0 .. x_{D-1}, x_0^2 .. x_{D-1}^2, 0 ...]
+//   MODEL = true  (Gaussians): [miv_0 .. miv_{D-1}, -0.5 iv_0 .. -0.5 iv_{D-1}, 0 ...]
+// so that score = gconst + <model row, feature row> (gmm/diag-gmm.cc:546-562).
+template <bool MODEL>
+__global__ void __launch_bounds__(256)
+    gmm_gemm_planes_kernel(const float *__restrict__ a, const float *__restrict__ b, int ld, int dim,
+                           int rows, uint4 *__restrict__ out, size_t pstride, int kp8) {
+  const size_t n = (size_t)rows * kp8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t oct = i / rows, r = i - oct * rows;
+    unsigned short p[3][8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int c = (int)oct * 8 + jj;
+      float v = 0.0f;
+      if (c < dim) {
+        v = a[r * ld + c];
+      } else if (c < 2 * dim) {
+        const float t = b[r * ld + (c - dim)];
+        v = MODEL ? -0.5f * t : t * t;
+      }
+      const __bf16 b1 = static_cast<__bf16>(v);
+      const float r1 = v - static_cast<float>(b1);
+      const __bf16 b2 = static_cast<__bf16>(r1);
+      const __bf16 b3 = static_cast<__bf16>(r1 - static_cast<float>(b2));
+      p[0][jj] = __builtin_bit_cast(unsigned short, b1);
+      p[1][jj] = __builtin_bit_cast(unsigned short, b2);
+      p[2][jj] = __builtin_bit_cast(unsigned short, b3);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      uint4 v;
+      v.x = p[q][0] | ((unsigned)p[q][1] << 16);
+      v.y = p[q][2] | ((unsigned)p[q][3] << 16);
+      v.z = p[q][4] | ((unsigned)p[q][5] << 16);
+      v.w = p[q][6] | ((unsigned)p[q][7] << 16);
+      out[q * pstride + i] = v;
+    }
+  }
+}
+
 // Per-Gaussian scores (DiagGmm::LogLikelihoods): out[t][g-g0] = gc + miv.x - 0.5 iv.x^2.
 // A 64-frame x 64-Gaussian tile per 256-thread block, operands staged in LDS,
 // each thread a 4x4 register block.  K is only 2*dim, so this is bound by the
@@ -1073,6 +1117,8 @@ __global__ void __launch_bounds__(256)
     gmm_pruned_lse_kernel(const float *__restrict__ scores, int ld,
                           const int32_t *__restrict__ offsets, int num_pdfs, int T, float prune,
                           float *__restrict__ out, int ldo, int *flag) {
+  // (Staging the block's stretch of the row through LDS first measured slower: the walk of
+  // each thread over its own pdf then conflicts on the LDS banks, while here it hits L1.)
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (p >= num_pdfs || t >= T) return;
@@ -1265,6 +1311,8 @@ struct amlike_gmm {
   bool profile = false;  // amlike_gmm_profile_kernel: event pairs around the scoring kernel
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
   size_t kev_used = 0;
+  void *d_wplanes = nullptr;  // per-Gaussian score GEMM: the model as bf16x3 planes (built on first use)
+  DeviceBuffer ws_xplanes;
   DeviceBuffer ws_raw;  // un-spliced features + speaker transform of amlike_gmm_score_raw
   DeviceBuffer ws_feats, ws_out, ws_part, ws_pad, ws_expand, ws_expand_safe, ws_fix, ws_gauss;
   std::mutex mu;
@@ -1875,6 +1923,8 @@ int amlike_gmm_destroy(amlike_gmm_t *g) {
   g->ws_gauss.Free();
   g->ws_feats.Free();
   g->ws_raw.Free();
+  g->ws_xplanes.Free();
+  (void)hipFree(g->d_wplanes);
   g->ws_out.Free();
   g->ws_part.Free();
   g->ws_pad.Free();
@@ -1903,9 +1953,12 @@ int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (log_sum_exp_prune > 0.0f) {
     // Pruning needs each pdf's maximum before its sum, so this mode goes through the
-    // per-Gaussian scores, in frame chunks that keep the scratch matrix near 1 GiB.
+    // per-Gaussian scores, in frame chunks that bound the scratch matrix.
     const int G = g->num_gauss;
-    const int chunk = std::max(64, (int)std::min<size_t>((size_t)T, ((size_t)1 << 28) / (size_t)G));
+    // (1 GiB: smaller chunks that would fit the memory-side cache measured slower.)
+    size_t budget = (size_t)1 << 28;  // floats
+    if (const char *e = getenv("AMLIKE_GMM_PRUNE_SCRATCH_MB")) budget = (size_t)std::max(1, atoi(e)) << 18;
+    const int chunk = std::max(64, (int)std::min<size_t>((size_t)T, budget / (size_t)G));
     rc = g->ws_gauss.Reserve((size_t)std::min(chunk, T) * G * sizeof(float));
     if (rc != AMLIKE_OK) return rc;
     float *scores = static_cast<float *>(g->ws_gauss.ptr);
@@ -2131,6 +2184,30 @@ int amlike_gmm_gauss_loglikes_dev(amlike_gmm_t *g, int32_t pdf_begin, int32_t pd
   if (T <= 0 || ld < feat_dim || ldo < g1 - g0) {
     SetError("amlike_gmm_gauss_loglikes: bad shape T=%d ld=%d ldo=%d", T, ld, ldo);
     return AMLIKE_EINVAL;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (T >= 64 && g1 - g0 >= 64 && !getenv("AMLIKE_GMM_GAUSS_VALU")) {
+    // A [T x 2D] . [2D x M] product with the gconsts as bias: the bf16x3 matrix-instruction
+    // GEMM of the nnet2 path, on plane images of the features (per call) and of the model
+    // (once per handle).
+    const int Kp = (2 * g->dim + 15) & ~15, kp8 = Kp >> 3;
+    const size_t G = (size_t)g->num_gauss;
+    if (!g->d_wplanes) {
+      AMLIKE_HIP(hipMalloc(&g->d_wplanes, 3 * G * kp8 * sizeof(uint4)));
+      const int blocks = (int)std::min<size_t>((G * kp8 + 255) / 256, 16384);
+      hipLaunchKernelGGL(gmm_gemm_planes_kernel<true>, dim3(blocks), dim3(256), 0, st, g->d_miv, g->d_iv,
+                         g->dim, g->dim, g->num_gauss, static_cast<uint4 *>(g->d_wplanes), G * kp8, kp8);
+      AMLIKE_HIP(hipGetLastError());
+    }
+    int rc = g->ws_xplanes.Reserve((size_t)3 * T * kp8 * sizeof(uint4));
+    if (rc != AMLIKE_OK) return rc;
+    const int blocks = (int)std::min<size_t>(((size_t)T * kp8 + 255) / 256, 16384);
+    hipLaunchKernelGGL(gmm_gemm_planes_kernel<false>, dim3(blocks), dim3(256), 0, st, d_feats, d_feats, ld,
+                       g->dim, T, static_cast<uint4 *>(g->ws_xplanes.ptr), (size_t)T * kp8, kp8);
+    AMLIKE_HIP(hipGetLastError());
+    return LaunchPlaneGemmBf16x3(g->ws_xplanes.ptr, (size_t)T * kp8,
+                                 static_cast<const uint4 *>(g->d_wplanes) + g0, G * kp8, G, Kp,
+                                 g->d_gconsts + g0, d_out, ldo, T, g1 - g0, st);
   }
   const size_t smem = (size_t)3 * 64 * (g->dim + 1) * sizeof(float);
   if (smem > 64 * 1024) {

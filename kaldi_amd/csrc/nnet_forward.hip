@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256)
 template <int PREC>
 __global__ void __launch_bounds__(256, 2)
     nnet_gemm_bias_planes_kernel(const uint4 *__restrict__ Xp, size_t xplane,
-                                 const uint4 *__restrict__ Wp, int Kp,
+                                 const uint4 *__restrict__ Wp, size_t wplane, size_t woct, int Kp,
                                  const float *__restrict__ bias, float *__restrict__ Y, int ldy,
                                  int M, int N) {
   constexpr int NPL = PREC ? 2 : 3, NPROD = PREC ? 3 : 6;
@@ -411,8 +411,9 @@ __global__ void __launch_bounds__(256, 2)
   const int kp8 = Kp >> 3, nk = Kp >> 4;
   // element of (row, octet o): o * rows + row
   const size_t xrow = (size_t)h * M + min(m0 + srow, M - 1);
-  const size_t wrow = (size_t)h * N + min(n0 + srow, N - 1);
-  const size_t wplane = (size_t)N * kp8;
+  // W may be a row range of a larger image: woct = rows of that image (the octet stride),
+  // wplane its plane stride
+  const size_t wrow = (size_t)h * woct + min(n0 + srow, N - 1);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -440,7 +441,7 @@ __global__ void __launch_bounds__(256, 2)
   for (int ks = 0; ks < nk; ++ks) {
     const int cur = ks & 1;
     if (ks + 1 < nk) {
-      const size_t ox = xrow + (size_t)(ks + 1) * 2 * M, ow = wrow + (size_t)(ks + 1) * 2 * N;
+      const size_t ox = xrow + (size_t)(ks + 1) * 2 * M, ow = wrow + (size_t)(ks + 1) * 2 * woct;
       rx0 = Xp[ox];
       rx1 = Xp[xplane + ox];
       rw0 = Wp[ow];
@@ -962,6 +963,20 @@ struct amlike_nnet {
 
 namespace amlike {
 
+int LaunchPlaneGemmBf16x3(const void *xp, size_t xplane, const void *wp, size_t wplane, size_t woct,
+                          int Kp, const float *bias, float *y, int ldy, int M, int N, hipStream_t st) {
+  if (M <= 0 || N <= 0 || (Kp & 15)) {
+    SetError("LaunchPlaneGemmBf16x3: bad shape");
+    return AMLIKE_EINVAL;
+  }
+  dim3 grid((N + 127) / 128, (M + 127) / 128);
+  hipLaunchKernelGGL(nnet_gemm_bias_planes_kernel<0>, grid, dim3(256), 0, st,
+                     static_cast<const uint4 *>(xp), xplane, static_cast<const uint4 *>(wp), wplane, woct,
+                     Kp, bias, y, ldy, M, N);
+  AMLIKE_HIP(hipGetLastError());
+  return AMLIKE_OK;
+}
+
 static void FreeNnet(amlike_nnet *n) {
   for (Stage &s : n->stages) {
     (void)hipFree(s.d_w);
@@ -1264,15 +1279,17 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
                              s.in_dim, (int)cur_rows, xp, -1);
           AMLIKE_HIP(hipGetLastError());
           hipLaunchKernelGGL(nnet_gemm_bias_planes_kernel<1>, grid, dim3(256), 0, st,
-                             static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo, s.Kp,
-                             s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
+                             static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo,
+                             (size_t)s.out_dim * (s.Kp / 8), (size_t)s.out_dim, s.Kp, s.d_bias, dst,
+                             dst_ld, (int)cur_rows, s.out_dim);
         } else {
           hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
                              s.in_dim, (int)cur_rows, xp, -1);
           AMLIKE_HIP(hipGetLastError());
           hipLaunchKernelGGL(nnet_gemm_bias_planes_kernel<0>, grid, dim3(256), 0, st,
-                             static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo, s.Kp,
-                             s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
+                             static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo,
+                             (size_t)s.out_dim * (s.Kp / 8), (size_t)s.out_dim, s.Kp, s.d_bias, dst,
+                             dst_ld, (int)cur_rows, s.out_dim);
         }
       }
       AMLIKE_HIP(hipGetLastError());
