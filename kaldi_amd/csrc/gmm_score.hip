@@ -880,6 +880,8 @@ __global__ void __launch_bounds__(64 * W, OCC)
               // timing experiment: the same number of store instructions, but 64 consecutive floats
               ar.out[(size_t)min(t0 + (col & 31), ar.T - 2) * ar.ldo + (col & ~31) + lane] = v;
             } else if (!(ABL & 1)) {
+              // (a non-temporal store here triples the kernel time: these 4-byte stores rely on
+              // L2 to merge the columns of neighbouring pdfs into full lines)
               orow[col] = v;
             } else {
               pin_order(v);

@@ -41,6 +41,8 @@ namespace amlike {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int RoundUp(int x, int m) { return (x + m - 1) / m * m; }
+// Results larger than this are streamed past the caches (non-temporal stores).
+constexpr size_t kStreamingBytes = (size_t)128 << 20;
 
 // Per-utterance bookkeeping of a batch: rows [in_off, in_off + in_rows) of the stage
 // input become rows [out_off, out_off + out_rows) of its output.
@@ -395,7 +397,11 @@ __global__ void __launch_bounds__(256)
 // (block tile 128 x 128, three blocks per CU), but both operand tiles are plain, fully
 // coalesced 16-byte copies global -> registers -> LDS.  (A 128 x 256 block tile with
 // 64 x 128 wave tiles was measured 15 % slower: it drops to two blocks per CU.)
-template <int PREC>
+// NT_STORE: the result is written with non-temporal stores, for results far larger than the
+// caches: a [35554 x 8600] result written normally evicts the operand planes from L2 while
+// the kernel still re-reads them (670 -> 525 us on that shape).  With the stores compiled out
+// the same launch takes 377 us, with a single k-step 316 us.
+template <int PREC, bool NT_STORE>
 __global__ void __launch_bounds__(256, 2)
     nnet_gemm_bias_planes_kernel(const uint4 *__restrict__ Xp, size_t xplane,
                                  const uint4 *__restrict__ Wp, size_t wplane, size_t woct, int Kp,
@@ -493,7 +499,10 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < M) Y[(size_t)m * ldy + n] = acc[mt][nt][r] + bv;
+        if (m < M) {
+          if (NT_STORE) __builtin_nontemporal_store(acc[mt][nt][r] + bv, &Y[(size_t)m * ldy + n]);
+          else Y[(size_t)m * ldy + n] = acc[mt][nt][r] + bv;
+        }
       }
   }
 }
@@ -781,6 +790,7 @@ __global__ void __launch_bounds__(256)
 // layer is: 8600).
 template <int R4>
 __global__ void __launch_bounds__(256)
+    // (non-temporal loads and stores make no difference here: 5.4 TB/s either way)
     nnet_softmax4_kernel(const float *__restrict__ in, int ld_in, int dim, int rows, int post,
                          const float *__restrict__ log_priors, float scale,
                          float *__restrict__ out, int ld_out, int zero_pad) {
@@ -970,7 +980,8 @@ int LaunchPlaneGemmBf16x3(const void *xp, size_t xplane, const void *wp, size_t 
     return AMLIKE_EINVAL;
   }
   dim3 grid((N + 127) / 128, (M + 127) / 128);
-  hipLaunchKernelGGL(nnet_gemm_bias_planes_kernel<0>, grid, dim3(256), 0, st,
+  const bool big_out = (size_t)M * N * sizeof(float) > kStreamingBytes;
+  hipLaunchKernelGGL((big_out ? nnet_gemm_bias_planes_kernel<0, true> : nnet_gemm_bias_planes_kernel<0, false>), grid, dim3(256), 0, st,
                      static_cast<const uint4 *>(xp), xplane, static_cast<const uint4 *>(wp), wplane, woct,
                      Kp, bias, y, ldy, M, N);
   AMLIKE_HIP(hipGetLastError());
@@ -1269,6 +1280,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
                            s.Kp, s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim);
       else {
         // the input as bf16x3 planes (one cheap pass), then the conversion-free GEMM
+        const bool big_out = (size_t)cur_rows * s.out_dim * sizeof(float) > kStreamingBytes;
         const size_t pstride = (size_t)cur_rows * s.Kp;
         rc = n->ws_planes.Reserve(3 * pstride * sizeof(unsigned short));
         if (rc != AMLIKE_OK) return rc;
@@ -1278,7 +1290,8 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
           hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
                              s.in_dim, (int)cur_rows, xp, -1);
           AMLIKE_HIP(hipGetLastError());
-          hipLaunchKernelGGL(nnet_gemm_bias_planes_kernel<1>, grid, dim3(256), 0, st,
+          hipLaunchKernelGGL((big_out ? nnet_gemm_bias_planes_kernel<1, true> : nnet_gemm_bias_planes_kernel<1, false>),
+                             grid, dim3(256), 0, st,
                              static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo,
                              (size_t)s.out_dim * (s.Kp / 8), (size_t)s.out_dim, s.Kp, s.d_bias, dst,
                              dst_ld, (int)cur_rows, s.out_dim);
@@ -1286,7 +1299,8 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
           hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
                              s.in_dim, (int)cur_rows, xp, -1);
           AMLIKE_HIP(hipGetLastError());
-          hipLaunchKernelGGL(nnet_gemm_bias_planes_kernel<0>, grid, dim3(256), 0, st,
+          hipLaunchKernelGGL((big_out ? nnet_gemm_bias_planes_kernel<0, true> : nnet_gemm_bias_planes_kernel<0, false>),
+                             grid, dim3(256), 0, st,
                              static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo,
                              (size_t)s.out_dim * (s.Kp / 8), (size_t)s.out_dim, s.Kp, s.d_bias, dst,
                              dst_ld, (int)cur_rows, s.out_dim);
