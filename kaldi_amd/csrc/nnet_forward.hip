@@ -352,10 +352,21 @@ __device__ __forceinline__ void store_planes(const Planes &o, size_t idx, float 
 // plane q, octet o (columns 8o .. 8o+7), row r is the 16-byte element q * stride/8 + o * rows + r.
 // With the rows of one octet contiguous, the GEMM's staging loads (32 rows x one octet per
 // half-wave) read 512 contiguous bytes instead of 16 bytes from each of 32 cache lines.
+// Layers whose input range is not known when the net is built run on fp16x2 operands "on
+// trial": the split pass raises *flag when a value does not fit (|x| > 32768, NaN, Inf), the
+// fp16x2 kernels (gmode 1) return at once when it is raised, and the bf16x3 twins launched
+// behind them (gmode 2) return at once when it is not.  No host round trip.
+__device__ __forceinline__ bool nnet_guard_skips(const int *flag, int gmode) {
+  if (gmode == 0) return false;
+  const bool raised = __builtin_nontemporal_load(flag) != 0;
+  return gmode == 1 ? raised : !raised;
+}
+
 template <int PREC>
 __global__ void __launch_bounds__(256)
     nnet_split_planes_kernel(const float *__restrict__ in, int ld, int dim, int rows, Planes out,
-                             int one_col) {
+                             int one_col, int *flag, int gmode) {
+  if (gmode == 2 && nnet_guard_skips(flag, 2)) return;
   const int kp8 = out.Kp >> 3;
   const size_t n = (size_t)rows * kp8;
   uint4 *o = reinterpret_cast<uint4 *>(out.p);
@@ -378,6 +389,13 @@ __global__ void __launch_bounds__(256)
       hi = make_float4(t[4], t[5], t[6], t[7]);
     }
     if (PREC) {
+      if (gmode == 1) {
+        const float m = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fmaxf(fabsf(lo.z), fabsf(lo.w))),
+                              fmaxf(fmaxf(fabsf(hi.x), fabsf(hi.y)), fmaxf(fabsf(hi.z), fabsf(hi.w))));
+        const bool fits = (lo.x == lo.x) & (lo.y == lo.y) & (lo.z == lo.z) & (lo.w == lo.w) &
+                          (hi.x == hi.x) & (hi.y == hi.y) & (hi.z == hi.z) & (hi.w == hi.w) & (m <= 32768.0f);
+        if (!fits) atomicOr(flag, 1);
+      }
       uint4 s0, s1;
       split_f16x2_8(lo, hi, s0, s1);
       o[i] = s0;
@@ -406,8 +424,9 @@ __global__ void __launch_bounds__(256, 2)
     nnet_gemm_bias_planes_kernel(const uint4 *__restrict__ Xp, size_t xplane,
                                  const uint4 *__restrict__ Wp, size_t wplane, size_t woct, int Kp,
                                  const float *__restrict__ bias, float *__restrict__ Y, int ldy,
-                                 int M, int N) {
+                                 int M, int N, const int *flag, int gmode) {
   constexpr int NPL = PREC ? 2 : 3, NPROD = PREC ? 3 : 6;
+  if (nnet_guard_skips(flag, gmode)) return;
   __shared__ __attribute__((aligned(16))) uint4 s_x[2][NPL][4][2][32];
   __shared__ __attribute__((aligned(16))) uint4 s_w[2][NPL][4][2][32];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -520,8 +539,10 @@ __global__ void __launch_bounds__(256, 2)
 template <int GS, int PREC>
 __global__ void __launch_bounds__(256, 2)
     nnet_gemm_pnorm_kernel(const uint4 *__restrict__ Xp, size_t xplane, const uint4 *__restrict__ Wp,
-                           int Kp, float *__restrict__ Y, int ldy, int M, int Npad, int G) {
+                           int Kp, float *__restrict__ Y, int ldy, int M, int Npad, int G,
+                           const int *flag, int gmode) {
   static_assert(80 % GS == 0, "a half-lane holds 80 units");
+  if (nnet_guard_skips(flag, gmode)) return;
   constexpr int NPL = PREC ? 2 : 3, NPROD = PREC ? 3 : 6;
   __shared__ __attribute__((aligned(16))) uint4 s_x[2][NPL][4][64];
   __shared__ __attribute__((aligned(16))) uint4 s_w[2][NPL][5][64];
@@ -731,9 +752,13 @@ __global__ void __launch_bounds__(256)
 constexpr int kPostFloorLog = 1;  // max(v, 1e-20) then log
 constexpr int kPostPrior = 2;     // minus log prior, times scale
 
+// ApplyFloor(1e-20) as the reference does it (matrix/kaldi-matrix.cc: `if (x < floor) x = floor`):
+// a NaN stays a NaN, where fmaxf would turn it into the floor.
+__device__ __forceinline__ float floor_1e20(float x) { return x < 1.0e-20f ? 1.0e-20f : x; }
+
 __device__ __forceinline__ float post_process(float v, int post, const float *log_priors, int c,
                                               float scale) {
-  if (post & kPostFloorLog) v = __logf(fmaxf(v, 1.0e-20f));
+  if (post & kPostFloorLog) v = __logf(floor_1e20(v));
   if (post & kPostPrior) v = (v - log_priors[c]) * scale;
   return v;
 }
@@ -779,7 +804,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int k = 0; k < kSoftmaxRegs; ++k) {
       const int c = t + k * 256;
-      if (c < dim) o[c] = post_process(fmaxf(v[k] * inv, 1.0e-20f), post, log_priors, c, scale);
+      if (c < dim) o[c] = post_process(floor_1e20(v[k] * inv), post, log_priors, c, scale);
       else if (zero_pad && c < ld_out) o[c] = 0.0f;
     }
   }
@@ -833,8 +858,8 @@ __global__ void __launch_bounds__(256)
     for (int k = 0; k < R4; ++k) {
       const int c = t + k * 256;
       if (c < dim4) {
-        float4 q = make_float4(fmaxf(v[k].x * inv, 1.0e-20f), fmaxf(v[k].y * inv, 1.0e-20f),
-                               fmaxf(v[k].z * inv, 1.0e-20f), fmaxf(v[k].w * inv, 1.0e-20f));
+        float4 q = make_float4(floor_1e20(v[k].x * inv), floor_1e20(v[k].y * inv),
+                               floor_1e20(v[k].z * inv), floor_1e20(v[k].w * inv));
         if (post & kPostFloorLog) q = make_float4(__logf(q.x), __logf(q.y), __logf(q.z), __logf(q.w));
         if (post & kPostPrior) {
           const float4 p = lp[c];
@@ -875,7 +900,7 @@ __global__ void __launch_bounds__(256)
     float *o = out + (size_t)r * ld_out;
     for (int c = t; c < ld_out; c += 256) {
       if (c < dim)
-        o[c] = post_process(fmaxf(__expf(x[c] - mx) * inv, 1.0e-20f), post, log_priors, c, scale);
+        o[c] = post_process(floor_1e20(__expf(x[c] - mx) * inv), post, log_priors, c, scale);
       else if (zero_pad) o[c] = 0.0f;
     }
   }
@@ -943,7 +968,11 @@ struct Stage {
   // affine followed by a p = 2 p-norm whose group size divides 80: the fused kernel's image
   uint4 *d_wpn = nullptr;   // rows permuted and padded to Npad, bias as column in_dim: [3][Kpn/8][Npad]
   int fuse_gs = 0, Kpn = 0, Npad = 0;
-  int f16 = 0;  // operands as fp16x2 (input behind a NormalizeComponent, weights inside the fp16 range)
+  // 1: operands as fp16x2 (input behind a NormalizeComponent, weights inside the fp16 range);
+  // 2: fp16x2 on trial (weights fit, input range unknown): d_wpo_safe / d_wpn_safe hold the
+  //    bf16x3 images the fallback kernels read
+  int f16 = 0;
+  uint4 *d_wpo_safe = nullptr, *d_wpn_safe = nullptr;
   std::vector<float> h_w, h_b;  // host copies kept until the next component is known
   float *d_bias = nullptr;
   int Kp = 0;
@@ -967,6 +996,7 @@ struct amlike_nnet {
   std::vector<UttMap> slot_utts[kAsyncSlots];  // the row maps a submission's upload reads
   int32_t next_ticket = 0;
   DeviceBuffer ws_a, ws_b, ws_in, ws_out, ws_utts, ws_planes;
+  int *d_flags = nullptr;  // one range flag per stage (fp16x2 on trial)
   std::vector<UttMap> h_utts;
   std::mutex mu;
 };
@@ -983,7 +1013,7 @@ int LaunchPlaneGemmBf16x3(const void *xp, size_t xplane, const void *wp, size_t 
   const bool big_out = (size_t)M * N * sizeof(float) > kStreamingBytes;
   hipLaunchKernelGGL((big_out ? nnet_gemm_bias_planes_kernel<0, true> : nnet_gemm_bias_planes_kernel<0, false>), grid, dim3(256), 0, st,
                      static_cast<const uint4 *>(xp), xplane, static_cast<const uint4 *>(wp), wplane, woct,
-                     Kp, bias, y, ldy, M, N);
+                     Kp, bias, y, ldy, M, N, nullptr, 0);
   AMLIKE_HIP(hipGetLastError());
   return AMLIKE_OK;
 }
@@ -994,10 +1024,13 @@ static void FreeNnet(amlike_nnet *n) {
     (void)hipFree(s.d_wp);
     (void)hipFree(s.d_wpo);
     (void)hipFree(s.d_wpn);
+    (void)hipFree(s.d_wpo_safe);
+    (void)hipFree(s.d_wpn_safe);
     (void)hipFree(s.d_bias);
     (void)hipFree(s.d_begins);
   }
   (void)hipFree(n->d_log_priors);
+  (void)hipFree(n->d_flags);
   n->ws_a.Free();
   n->ws_b.Free();
   n->ws_in.Free();
@@ -1156,6 +1189,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
     AMLIKE_HIP(hipMemcpyAsync(n->ws_utts.ptr, maps.data(), maps.size() * sizeof(UttMap),
                               hipMemcpyHostToDevice, st));
   const UttMap *d_maps = static_cast<const UttMap *>(n->ws_utts.ptr);
+  AMLIKE_HIP(hipMemsetAsync(n->d_flags, 0, (n->stages.size() + 1) * sizeof(int), st));
 
   const float *cur = d_feats;
   int cur_ld = ld;
@@ -1211,17 +1245,21 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       const Stage &pn = n->stages[si + 1];
       const bool pn_last = (si + 2 == ns);
       const size_t pstride = (size_t)cur_rows * s.Kpn;
-      rc = n->ws_planes.Reserve(3 * pstride * sizeof(unsigned short));
+      // fp16x2 on trial keeps both plane images: [2 planes fp16][3 planes bf16]
+      rc = n->ws_planes.Reserve((s.f16 == 2 ? 5 : 3) * pstride * sizeof(unsigned short));
       if (rc != AMLIKE_OK) return rc;
-      Planes xp{static_cast<unsigned short *>(n->ws_planes.ptr), pstride, s.Kpn};
+      unsigned short *pbase = static_cast<unsigned short *>(n->ws_planes.ptr);
+      int *flag = n->d_flags + si;
       const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
-      if (s.f16)
-        hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
-                           s.in_dim, (int)cur_rows, xp, s.in_dim);
-      else
-        hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
-                           s.in_dim, (int)cur_rows, xp, s.in_dim);
-      AMLIKE_HIP(hipGetLastError());
+      auto split = [&](int prec, unsigned short *dstp, int gmode) {
+        Planes xp{dstp, pstride, s.Kpn};
+        if (prec)
+          hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                             s.in_dim, (int)cur_rows, xp, s.in_dim, flag, gmode);
+        else
+          hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                             s.in_dim, (int)cur_rows, xp, s.in_dim, flag, gmode);
+      };
       const int G = pn.out_dim;
       // without a Normalize the p-norm output is this pair's result; with one it goes to the
       // other scratch buffer first
@@ -1229,16 +1267,31 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       float *pdst = norm ? bufs[which] : (pn_last ? d_out : bufs[which]);
       const int pld = norm ? RoundUp(G, 16) : (pn_last ? ldo : RoundUp(G, 16));
       dim3 fgrid(s.Npad / 160, (unsigned)((cur_rows + 127) / 128));
-      const uint4 *xpl = static_cast<const uint4 *>(n->ws_planes.ptr);
-#define AMLIKE_PNORM_LAUNCH(GS, PREC)                                                              \
-  hipLaunchKernelGGL((nnet_gemm_pnorm_kernel<GS, PREC>), fgrid, dim3(256), 0, st, xpl, pstride / 8,   \
-                     s.d_wpn, s.Kpn, pdst, pld, (int)cur_rows, s.Npad, G)
-      if (s.fuse_gs == 10 && s.f16) AMLIKE_PNORM_LAUNCH(10, 1);
-      else if (s.fuse_gs == 10) AMLIKE_PNORM_LAUNCH(10, 0);
-      else if (s.fuse_gs == 5 && s.f16) AMLIKE_PNORM_LAUNCH(5, 1);
-      else if (s.fuse_gs == 5) AMLIKE_PNORM_LAUNCH(5, 0);
-      else if (s.f16) AMLIKE_PNORM_LAUNCH(8, 1);
-      else AMLIKE_PNORM_LAUNCH(8, 0);
+#define AMLIKE_PNORM_LAUNCH(GS, PREC, XPL, WPN, GMODE)                                            \
+  hipLaunchKernelGGL((nnet_gemm_pnorm_kernel<GS, PREC>), fgrid, dim3(256), 0, st,                \
+                     reinterpret_cast<const uint4 *>(XPL), pstride / 8, WPN, s.Kpn, pdst, pld,    \
+                     (int)cur_rows, s.Npad, G, flag, GMODE)
+      auto fused = [&](int prec, const unsigned short *xpl, const uint4 *wpn, int gmode) {
+        if (s.fuse_gs == 10 && prec) AMLIKE_PNORM_LAUNCH(10, 1, xpl, wpn, gmode);
+        else if (s.fuse_gs == 10) AMLIKE_PNORM_LAUNCH(10, 0, xpl, wpn, gmode);
+        else if (s.fuse_gs == 5 && prec) AMLIKE_PNORM_LAUNCH(5, 1, xpl, wpn, gmode);
+        else if (s.fuse_gs == 5) AMLIKE_PNORM_LAUNCH(5, 0, xpl, wpn, gmode);
+        else if (prec) AMLIKE_PNORM_LAUNCH(8, 1, xpl, wpn, gmode);
+        else AMLIKE_PNORM_LAUNCH(8, 0, xpl, wpn, gmode);
+      };
+      if (s.f16 == 2) {
+        split(1, pbase, 1);
+        AMLIKE_HIP(hipGetLastError());
+        fused(1, pbase, s.d_wpn, 1);
+        AMLIKE_HIP(hipGetLastError());
+        split(0, pbase + 2 * pstride, 2);
+        AMLIKE_HIP(hipGetLastError());
+        fused(0, pbase + 2 * pstride, s.d_wpn_safe, 2);
+      } else {
+        split(s.f16, pbase, 0);
+        AMLIKE_HIP(hipGetLastError());
+        fused(s.f16, pbase, s.d_wpn, 0);
+      }
 #undef AMLIKE_PNORM_LAUNCH
       AMLIKE_HIP(hipGetLastError());
       float *fin = pdst;
@@ -1282,28 +1335,35 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         // the input as bf16x3 planes (one cheap pass), then the conversion-free GEMM
         const bool big_out = (size_t)cur_rows * s.out_dim * sizeof(float) > kStreamingBytes;
         const size_t pstride = (size_t)cur_rows * s.Kp;
-        rc = n->ws_planes.Reserve(3 * pstride * sizeof(unsigned short));
+        rc = n->ws_planes.Reserve((s.f16 == 2 ? 5 : 3) * pstride * sizeof(unsigned short));
         if (rc != AMLIKE_OK) return rc;
-        Planes xp{static_cast<unsigned short *>(n->ws_planes.ptr), pstride, s.Kp};
+        unsigned short *pbase = static_cast<unsigned short *>(n->ws_planes.ptr);
+        int *flag = n->d_flags + si;
         const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
-        if (s.f16) {
-          hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
-                             s.in_dim, (int)cur_rows, xp, -1);
+        auto split_gemm = [&](int prec, unsigned short *xpl, const uint4 *wpo, int gmode) {
+          Planes xp{xpl, pstride, s.Kp};
+          const uint4 *x4 = reinterpret_cast<const uint4 *>(xpl);
+          const size_t wplane = (size_t)s.out_dim * (s.Kp / 8);
+          if (prec) {
+            hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                               s.in_dim, (int)cur_rows, xp, -1, flag, gmode);
+            hipLaunchKernelGGL((big_out ? nnet_gemm_bias_planes_kernel<1, true> : nnet_gemm_bias_planes_kernel<1, false>),
+                               grid, dim3(256), 0, st, x4, pstride / 8, wpo, wplane, (size_t)s.out_dim, s.Kp,
+                               s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim, flag, gmode);
+          } else {
+            hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                               s.in_dim, (int)cur_rows, xp, -1, flag, gmode);
+            hipLaunchKernelGGL((big_out ? nnet_gemm_bias_planes_kernel<0, true> : nnet_gemm_bias_planes_kernel<0, false>),
+                               grid, dim3(256), 0, st, x4, pstride / 8, wpo, wplane, (size_t)s.out_dim, s.Kp,
+                               s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim, flag, gmode);
+          }
+        };
+        if (s.f16 == 2) {
+          split_gemm(1, pbase, s.d_wpo, 1);
           AMLIKE_HIP(hipGetLastError());
-          hipLaunchKernelGGL((big_out ? nnet_gemm_bias_planes_kernel<1, true> : nnet_gemm_bias_planes_kernel<1, false>),
-                             grid, dim3(256), 0, st,
-                             static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo,
-                             (size_t)s.out_dim * (s.Kp / 8), (size_t)s.out_dim, s.Kp, s.d_bias, dst,
-                             dst_ld, (int)cur_rows, s.out_dim);
+          split_gemm(0, pbase + 2 * pstride, s.d_wpo_safe, 2);
         } else {
-          hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
-                             s.in_dim, (int)cur_rows, xp, -1);
-          AMLIKE_HIP(hipGetLastError());
-          hipLaunchKernelGGL((big_out ? nnet_gemm_bias_planes_kernel<0, true> : nnet_gemm_bias_planes_kernel<0, false>),
-                             grid, dim3(256), 0, st,
-                             static_cast<const uint4 *>(n->ws_planes.ptr), pstride / 8, s.d_wpo,
-                             (size_t)s.out_dim * (s.Kp / 8), (size_t)s.out_dim, s.Kp, s.d_bias, dst,
-                             dst_ld, (int)cur_rows, s.out_dim);
+          split_gemm(s.f16, pbase, s.d_wpo, 0);
         }
       }
       AMLIKE_HIP(hipGetLastError());
@@ -1450,11 +1510,18 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
           float wmax = 0.0f;
           for (float v : w) wmax = std::max(wmax, std::fabs(v));
           for (int r = 0; r < c.output_dim; ++r) wmax = std::max(wmax, std::fabs(c.bias[r]));
-          s.f16 = i > 0 && comps[i - 1].kind == AMLIKE_NORMALIZE && std::isfinite(wmax) &&
-                  wmax <= 1024.0f && !getenv("AMLIKE_NNET_NOF16");
+          const bool w_ok = std::isfinite(wmax) && wmax <= 1024.0f && !getenv("AMLIKE_NNET_NOF16");
+          const bool normalised_input = i > 0 && comps[i - 1].kind == AMLIKE_NORMALIZE;
+          s.f16 = !w_ok ? 0 : normalised_input ? 1 : (getenv("AMLIKE_NNET_NOF16TRY") ? 0 : 2);
         }
         std::vector<uint16_t> wpo = BuildPlaneWeights(w, s.Kp, c.output_dim, s.f16);
         hipError_t e = hipMalloc(&s.d_w, w.size() * sizeof(float));
+        if (e == hipSuccess && s.f16 == 2) {  // the bf16x3 image for the fallback
+          std::vector<uint16_t> safe = BuildPlaneWeights(w, s.Kp, c.output_dim, 0);
+          e = hipMalloc(&s.d_wpo_safe, safe.size() * sizeof(uint16_t));
+          if (e == hipSuccess)
+            e = hipMemcpy(s.d_wpo_safe, safe.data(), safe.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+        }
         if (e == hipSuccess) e = hipMalloc(&s.d_wpo, wpo.size() * sizeof(uint16_t));
         if (e == hipSuccess)
           e = hipMemcpy(s.d_wpo, wpo.data(), wpo.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
@@ -1488,6 +1555,14 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
             hipError_t e = hipMalloc(&a.d_wpn, img.size() * sizeof(uint16_t));
             if (e == hipSuccess)
               e = hipMemcpy(a.d_wpn, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+            if (e == hipSuccess && a.f16 == 2) {
+              int kpn2 = 0, npad2 = 0;
+              std::vector<uint16_t> safe = BuildPnormWeights(a.h_w, a.Kp, a.h_b, a.out_dim, a.in_dim, 0,
+                                                             &kpn2, &npad2);
+              e = hipMalloc(&a.d_wpn_safe, safe.size() * sizeof(uint16_t));
+              if (e == hipSuccess)
+                e = hipMemcpy(a.d_wpn_safe, safe.data(), safe.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+            }
             if (e != hipSuccess) {
               SetError("amlike_nnet_create: %s", hipGetErrorString(e));
               rc = e == hipErrorOutOfMemory ? AMLIKE_EOOM : AMLIKE_EHIP;
@@ -1537,6 +1612,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
       (void)hipFree(s.d_w);
       (void)hipFree(s.d_wp);
       (void)hipFree(s.d_wpo);
+      (void)hipFree(s.d_wpo_safe);
       (void)hipFree(s.d_bias);
       (void)hipFree(s.d_begins);
       break;
@@ -1566,6 +1642,13 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
       rc = AMLIKE_EHIP;
     }
     n->num_priors = num_priors;
+  }
+  if (rc == AMLIKE_OK) {
+    hipError_t e = hipMalloc(&n->d_flags, (n->stages.size() + 1) * sizeof(int));
+    if (e != hipSuccess) {
+      SetError("amlike_nnet_create: %s", hipGetErrorString(e));
+      rc = AMLIKE_EHIP;
+    }
   }
   if (rc == AMLIKE_OK) {
     hipError_t e = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking);

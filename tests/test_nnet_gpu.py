@@ -165,3 +165,33 @@ def test_submit_wait_matches_the_synchronous_call(amlike_device, pad):
             submit(i + 2)
     for p in pin_in + pin_out:
         p.close()
+
+
+def test_fp16_operands_on_trial_fall_back_when_the_input_does_not_fit(amlike_device, monkeypatch):
+    """Layers whose input is not behind a NormalizeComponent (the LDA-like first affine layers)
+    use fp16x2 operands only if every input value fits; one value beyond 32768 (or a NaN)
+    switches that call to the bf16x3 kernels, decided on the device."""
+    comps, priors = _nets()["mid"]
+    rng = np.random.default_rng(91)
+    x = rng.normal(size=(300, 40)).astype(np.float32)
+    x_big = x.copy()
+    x_big[17, 3] = 5.0e4
+    x_big[250, 39] = -3.0e5
+    trial = nnet.AmNnet(comps, priors)
+    monkeypatch.setenv("AMLIKE_NNET_NOF16TRY", "1")
+    plain = nnet.AmNnet(comps, priors)  # the first layers on bf16x3 operands, no trial
+    monkeypatch.delenv("AMLIKE_NNET_NOF16TRY")
+    for mode, tol in ((nnet.POSTERIORS, 1e-5), (nnet.LOGLIKES, 1e-3)):
+        want = oracle.nnet_compute(comps, priors, x, True, mode, 1.0)
+        got = trial.Compute(x, mode=mode)
+        assert np.abs(got - want).max() < tol
+        assert np.abs(plain.Compute(x, mode=mode) - want).max() < tol
+        # out-of-range input: the very kernels of the plain handle run, so the bits agree
+        np.testing.assert_array_equal(trial.Compute(x_big, mode=mode), plain.Compute(x_big, mode=mode))
+        # and the next call with ordinary input is back on the fast path, unaffected
+        np.testing.assert_array_equal(trial.Compute(x, mode=mode), got)
+    x_nan = x.copy()
+    x_nan[5, 0] = np.nan
+    a, b = trial.Compute(x_nan), plain.Compute(x_nan)
+    assert np.isnan(a[:10]).any()
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
