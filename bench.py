@@ -168,10 +168,10 @@ def main():
     traffic = traffic_detail = None
     if args.config == "swbd_tri4" and "gmm_score_diff_kernel<5,2,8,2,f16x2>" in am.kernel_info() \
             and T == 35554:
-        traffic = 2.0 * 616323e3 + 1265390e3
-        traffic_detail = {"fetch_bytes": 2.0 * 616323e3, "write_bytes": 1265390e3,
+        traffic = 2.0 * 611329e3 + 1324680e3
+        traffic_detail = {"fetch_bytes": 2.0 * 611329e3, "write_bytes": 1324680e3,
                           "algorithmic_bytes": 4.0 * T * P + 4.0 * T * D,
-                          "source": "profiles/r1_e_gmm_diff_pmc_summary.txt"}
+                          "source": "profiles/r1_g_gmm_diff_pmc_summary.txt"}
 
     if rank == 0:
         value = tot_frames * args.steps / elapsed

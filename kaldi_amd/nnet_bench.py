@@ -7,7 +7,11 @@ import torch
 
 from . import nnet, synth
 
-FP32_MFMA_PEAK_TFLOPS = 157.3
+# The layers run on fp16x2 operands (3 partial products per fp32-grade product) of the fp16
+# matrix pipe, 2500 TFLOP/s dense; the output layer and the softmax are bound by the
+# [T x 8600] matrix they stream instead (written, read, written: 12 bytes per element).
+F16X2_PEAK_TFLOPS = 2500.0 / 3.0
+HBM_PEAK_TBS = 8.0
 
 
 def run(dev, stream, world, utts_per_gpu=40, steps=10, warmup=2, rank=0):
@@ -42,9 +46,11 @@ def run(dev, stream, world, utts_per_gpu=40, steps=10, warmup=2, rank=0):
                     "-> normalize) -> 8600 softmax, log, minus log-prior; %d utterances, %d frames per step" % (len(lengths), T),
         "frames_per_sec_per_gpu": T / dt, "ms_per_step": dt * 1e3,
         "gemm_flop_per_frame": flop_per_frame,
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "note": "whole forward pass (GEMMs + row kernels) against the fp32 MFMA peak"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": F16X2_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / F16X2_PEAK_TFLOPS,
+                     "note": "whole forward pass (GEMMs + row kernels) against the fp16 matrix peak / 3 "
+                             "partial products; the pass also streams 12 bytes per output element",
+                     "hbm_floor_ms": 12.0 * T * P / (HBM_PEAK_TBS * 1e12) * 1e3},
     }
     net.close()
     return res
