@@ -15,8 +15,11 @@ data-path collective.  After the timed region the ranks all-reduce (RCCL)
 reference binaries log.
 
 The line also carries
-  roofline      dominant kernel's algorithmic FLOP / its mean duration measured
-                with HIP events on the launch stream, against the fp32 MFMA peak;
+  roofline      dominant kernel's algorithmic FLOP / its mean duration, measured with HIP
+                events around that kernel in every timed step (on the launch stream), against
+                the 16-bit matrix peak divided by the partial products one fp32-grade product
+                takes (3 for the default fp16x2 operands); traffic = HBM bytes per launch from
+                rocprofv3 PMC passes of the same workload;
   cpu_baseline  the real reference library (oracle/_ref, kind "reference") or the
                 C restatement (kind "port") timed on a bounded sample, rank 0, N=1.
 """
@@ -38,8 +41,8 @@ from kaldi_amd.sharding import reduce_summary, shard_utterances
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16)
-# The shipped kernel forms every fp32-grade product from 6 bf16 partial products
-# (bf16x3 split of both operands), so the matrix pipe bounds it at peak / 6.
+# bf16x3 operands (the wide-range kernels): every fp32-grade product is 6 bf16 partial products,
+# so the matrix pipe bounds them at peak / 6.
 BF16X3_PRODUCTS = 6
 # The default kernel uses fp16x2 operands (same matrix rate as bf16): 3 partial products.
 F16X2_PRODUCTS = 3

@@ -10,25 +10,30 @@
 //
 // Formulation.  For Gaussian g and frame t
 //   f[g,t] = gconst_g + sum_d miv[g,d] x[t,d] + sum_d (-0.5 iv[g,d]) x[t,d]^2
-// is a [G x 2D] . [2D x T] contraction.  It runs on the exact-fp32 matrix
-// instruction v_mfma_f32_32x32x2_f32: one instruction per feature dimension d,
-// whose two k-slots are (miv_d, x_d) and (-0.5 iv_d, x_d^2), with gconst as the
-// initial accumulator -- the same order of fp32 fused multiply-adds as
-// "ll = gconsts; ll += miv.x; ll += -0.5 iv.x^2", no padding of K.
+// is a [G x 2D] . [2D x T] contraction followed by a log-sum-exp over each pdf's Gaussians.
+// Three kernel families compute it, all with the same layout:
+//   gmm_score_diff_kernel    (default) 16-bit matrix instructions on split operands (fp16x2:
+//                            3 partial products, or bf16x3: 6), the model packed relative to
+//                            one reference Gaussian per pdf so that the log-sum-exp is one exp
+//                            and one fma per element; see the comment at the kernel;
+//   gmm_score_bf16x3_kernel  bf16x3 operands, running (max, sum) log-sum-exp: the wide-range
+//                            fallback the default kernel hands over to (decided on the device);
+//   gmm_score_kernel         the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32, one per
+//                            feature dimension, gconst as the initial accumulator: the same
+//                            order of fp32 fused multiply-adds as "ll = gconsts; ll += miv.x;
+//                            ll += -0.5 iv.x^2".  Kept as an independent check (AMLIKE_GMM_MODE=f32).
 //
 // Layout.  MODEL-STATIONARY: a wave keeps the A operands of NT tiles of 32
-// Gaussians in registers for its whole life (NT*D VGPRs) and streams 32-frame
-// tiles of features past them; the model is read from HBM once per block, the
-// features (160 B/frame) come from L2.  Frames sit on the MFMA's lane axis and
-// Gaussians on its register axis, so the per-pdf log-sum-exp is a running
-// (max, sum) in two registers per lane with no cross-lane traffic until a pdf
-// ends; then the two half-waves are merged with two v_permlane32_swap and lanes
-// 0-31 store the pdf's value for their 32 frames.  The [T x G] matrix of
+// Gaussians in registers for its whole life and streams 32-frame tiles of features past
+// them; the model is read from HBM once per block, the features come from L2 through LDS.
+// Frames sit on the matrix instruction's lane axis and Gaussians on its register axis, so
+// the per-pdf log-sum-exp is per-lane arithmetic over a lane's own accumulator registers with
+// no cross-lane traffic until a pdf ends; then the two half-waves are merged with
+// v_permlane32_swap and the pdf's value for 32 frames is stored.  The [T x G] matrix of
 // per-Gaussian scores never exists in memory.
 //
-// Software pipeline: while the 16 accumulator registers of tile k go through
-// the (max,sum) update on the VALU, the D matrix instructions of tile k+1 are
-// issued between them (source order: ~D/16 MFMAs, one update, repeat).
+// Software pipeline: while the accumulator registers of tile k go through the log-sum-exp
+// update on the VALU, the matrix instructions of tile k+1 are issued between them.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
