@@ -1685,8 +1685,8 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
   int target = 2048;
   if (const char *e = getenv("AMLIKE_GMM_FPB")) target = std::max(32, atoi(e));  // tuning aid
   int nby = std::max(1, (T + target - 1) / target);
-  // Small batches: split the frames further so that at least ~2 blocks per CU exist.
-  while (nbx * nby < 2 * cus && (T + nby - 1) / nby > 64) ++nby;
+  // Small batches: split the frames further so that every CU has a block.
+  while (nbx * nby < cus && (T + nby - 1) / nby > 64) ++nby;
   // One block per CU runs at a time, so the launch takes ceil(blocks / CUs) rounds of
   // (frames per block + start-up); pick the split near the target that wastes least of
   // the last round.  The start-up (loading the operand registers) costs about as much as
@@ -1694,7 +1694,7 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
   if (!getenv("AMLIKE_GMM_FPB")) {
     double best_cost = 0.0;
     int best = nby;
-    for (int cand = std::max(1, nby - nby / 4); cand <= nby + nby / 3 + 1; ++cand) {
+    for (int cand = std::max(1, nby - nby / 4); cand <= std::max(nby + nby / 3 + 1, 6); ++cand) {
       const int f = ((T + cand - 1) / cand + 31) & ~31;
       if (f < 64) break;
       const int nb = nbx * ((T + f - 1) / f);
