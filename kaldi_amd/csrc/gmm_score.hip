@@ -1784,7 +1784,7 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
     rc = pass(v.kernel, v.expand, v.prec ? 2 : 3, g->d_apack, g->d_gcpack, &g->ws_expand, 1);
     if (rc != AMLIKE_OK) return rc;
     if (v.mode >= 300) return AMLIKE_OK;  // timing experiments: the main kernel alone
-    hipLaunchKernelGGL(gmm_fix_kernel, dim3(64), dim3(256), 0, stream, g->d_ctl, ar.fix_list, ar.fix_cap,
+    hipLaunchKernelGGL(gmm_fix_kernel, dim3(1024), dim3(256), 0, stream, g->d_ctl, ar.fix_list, ar.fix_cap,
                        g->d_gconsts, g->d_miv, g->d_iv, g->d_offsets, g->dim, d_feats, ld, d_out, ldo,
                        g->d_flag);
     AMLIKE_HIP(hipGetLastError());

@@ -410,3 +410,36 @@ def test_swbd_tri4_full_size(amlike_device, monkeypatch):
     assert "gmm_score_kernel" in am32.kernel_info()
     assert np.abs(ref - got).max() <= TOL
     assert (ref.argmax(1) == got.argmax(1)).mean() >= 0.9999
+
+
+def test_threads_sharing_one_handle_and_threads_with_their_own(amlike_device):
+    """The *-parallel binaries of the reference score from several threads over one shared model
+    (gmmbin/gmm-latgen-faster-parallel.cc:138-155).  Host-pointer calls on one handle are
+    serialised inside the library; separate handles run concurrently.  Either way every thread
+    gets the bits a lone call gets."""
+    import threading
+    m = synth.make_gmm(40, 200, 3000, seed=81)
+    shared = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    own = [gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"]) for _ in range(3)]
+    feats = [synth.make_feats(m, 200 + 131 * i, seed=90 + i) for i in range(6)]
+    want = [shared.LogLikelihoods(f) for f in feats]
+    results, errors = {}, []
+
+    def work(tag, am, idx):
+        try:
+            for rep in range(5):
+                for i in idx:
+                    results[(tag, i, rep)] = am.LogLikelihoods(feats[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=("s%d" % t, shared, [t, t + 3])) for t in range(3)]
+    threads += [threading.Thread(target=work, args=("o%d" % t, own[t], [t, 5 - t])) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 6 * 2 * 5
+    for (tag, i, rep), got in results.items():
+        np.testing.assert_array_equal(got, want[i])
