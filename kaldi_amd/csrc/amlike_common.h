@@ -21,6 +21,10 @@ const char *LastError();
 // The device every handle of this process is bound to (amlike_init).
 int CurrentDevice();
 int NumComputeUnits();
+// Makes the process's device (amlike_init) current on the calling thread: HIP's current device
+// is per thread and starts at 0, so a thread other than the one that called amlike_init would
+// otherwise work on the wrong GPU.  No-op before amlike_init.
+int BindThread();
 
 // Growable device buffer owned by a handle.  Never shrinks.
 struct DeviceBuffer {

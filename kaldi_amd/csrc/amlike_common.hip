@@ -20,6 +20,14 @@ const char *LastError() { return g_err; }
 int CurrentDevice() { return g_device; }
 int NumComputeUnits() { return g_num_cu; }
 
+int BindThread() {
+  if (g_device < 0) return AMLIKE_OK;
+  int cur = -1;
+  AMLIKE_HIP(hipGetDevice(&cur));
+  if (cur != g_device) AMLIKE_HIP(hipSetDevice(g_device));
+  return AMLIKE_OK;
+}
+
 int DeviceBuffer::Reserve(size_t want) {
   if (want <= bytes) return AMLIKE_OK;
   if (ptr) {
@@ -111,6 +119,7 @@ int amlike_host_alloc(size_t bytes, void **ptr) {
     return AMLIKE_EINVAL;
   }
   *ptr = nullptr;
+  if (int brc = amlike::BindThread()) return brc;
   hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
   if (e != hipSuccess) {
     (void)hipGetLastError();

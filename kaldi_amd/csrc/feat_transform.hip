@@ -97,6 +97,7 @@ extern "C" {
 
 int amlike_xform_create(int32_t dim, int32_t left, int32_t right, const float *mat, int32_t rows,
                         int32_t cols, amlike_xform_t **out) {
+  if (int brc = BindThread()) return brc;
   const int sdim = dim * (left + right + 1);
   if (!out || dim <= 0 || left < 0 || right < 0 || (mat && (rows <= 0 || rows > kXformMaxRows)) ||
       (!mat && sdim > kXformMaxRows)) {
@@ -134,6 +135,7 @@ int amlike_xform_create(int32_t dim, int32_t left, int32_t right, const float *m
 }
 
 int amlike_xform_destroy(amlike_xform_t *x) {
+  if (int brc = BindThread()) return brc;
   if (!x) return AMLIKE_OK;
   (void)hipFree(x->d_mat);
   x->ws_off.Free();
@@ -155,6 +157,7 @@ int amlike_xform_apply_dev(amlike_xform_t *x, const float *d_in, int32_t ld,
                            const int32_t *utt_rows, int32_t num_utts, const float *d_spk_mats,
                            int32_t rows2, int32_t cols2, const int32_t *utt_mat, float *d_out,
                            int32_t ldo, void *stream) {
+  if (int brc = BindThread()) return brc;
   if (!x || !d_in || !d_out || !utt_rows || num_utts <= 0 || ld < x->dim) {
     SetError("amlike_xform_apply: invalid argument");
     return AMLIKE_EINVAL;
@@ -217,6 +220,7 @@ int amlike_xform_apply_dev(amlike_xform_t *x, const float *d_in, int32_t ld,
 
 int amlike_xform_apply(amlike_xform_t *x, const float *feats, int32_t T, int32_t ld,
                        const float *spk_mat, int32_t rows2, int32_t cols2, float *out, int32_t ldo) {
+  if (int brc = BindThread()) return brc;
   if (!x || !feats || !out || T <= 0 || ld < x->dim) {
     SetError(T <= 0 ? "SpliceFrames: empty input" : "amlike_xform_apply: invalid argument");
     return AMLIKE_EINVAL;

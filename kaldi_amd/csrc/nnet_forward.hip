@@ -1443,6 +1443,7 @@ extern "C" {
 
 int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float *priors,
                        int32_t num_priors, amlike_nnet_t **out) {
+  if (int brc = BindThread()) return brc;
   if (!comps || num <= 0 || !out) {
     SetError("amlike_nnet_create: invalid argument");
     return AMLIKE_EINVAL;
@@ -1666,6 +1667,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
 }
 
 int amlike_nnet_destroy(amlike_nnet_t *n) {
+  if (int brc = BindThread()) return brc;
   if (n) FreeNnet(n);
   return AMLIKE_OK;
 }
@@ -1678,6 +1680,7 @@ int amlike_nnet_compute_batch_dev(amlike_nnet_t *n, const float *d_feats, int32_
                                   const int32_t *utt_rows, int32_t num_utts, int32_t pad_input,
                                   int32_t mode, float prob_scale, float *d_out, int32_t ldo,
                                   void *stream, int64_t *total_out_rows) {
+  if (int brc = BindThread()) return brc;
   if (!n || !d_feats || !d_out || !utt_rows || num_utts <= 0 || ld < n->input_dim ||
       ldo < n->output_dim || mode < 0 || mode > 2) {
     SetError("amlike_nnet_compute: invalid argument");
@@ -1690,12 +1693,14 @@ int amlike_nnet_compute_batch_dev(amlike_nnet_t *n, const float *d_feats, int32_
 int amlike_nnet_compute_dev(amlike_nnet_t *n, const float *d_feats, int32_t T, int32_t ld,
                             int32_t pad_input, int32_t mode, float prob_scale, float *d_out,
                             int32_t ldo, void *stream) {
+  if (int brc = BindThread()) return brc;
   return amlike_nnet_compute_batch_dev(n, d_feats, ld, &T, 1, pad_input, mode, prob_scale, d_out,
                                        ldo, stream, nullptr);
 }
 
 int amlike_nnet_compute(amlike_nnet_t *n, const float *feats, int32_t T, int32_t ld,
                         int32_t pad_input, int32_t mode, float prob_scale, float *out, int32_t ldo) {
+  if (int brc = BindThread()) return brc;
   if (!n || !feats || !out || T <= 0 || ld < n->input_dim || ldo < n->output_dim) {
     SetError("amlike_nnet_compute: invalid argument");
     return AMLIKE_EINVAL;
@@ -1740,6 +1745,7 @@ int amlike_nnet_compute(amlike_nnet_t *n, const float *feats, int32_t T, int32_t
 int amlike_nnet_compute_submit(amlike_nnet_t *n, const float *feats, int32_t T, int32_t ld,
                                int32_t pad_input, int32_t mode, float prob_scale, float *out,
                                int32_t ldo, int32_t *ticket) {
+  if (int brc = BindThread()) return brc;
   if (!n || !feats || !out || !ticket || T <= 0 || ld < n->input_dim || ldo < n->output_dim) {
     SetError("amlike_nnet_compute_submit: invalid argument");
     return AMLIKE_EINVAL;
@@ -1804,6 +1810,7 @@ int amlike_nnet_compute_submit(amlike_nnet_t *n, const float *feats, int32_t T, 
 }
 
 int amlike_nnet_compute_wait(amlike_nnet_t *n, int32_t ticket) {
+  if (int brc = BindThread()) return brc;
   if (!n || ticket < 0) {
     SetError("amlike_nnet_compute_wait: invalid argument");
     return AMLIKE_EINVAL;
@@ -1827,6 +1834,7 @@ int amlike_nnet_compute_wait(amlike_nnet_t *n, int32_t ticket) {
 int amlike_nnet_time_compute_dev(amlike_nnet_t *n, const float *d_feats, int32_t T, int32_t ld,
                                  int32_t pad_input, int32_t mode, float prob_scale, float *d_out,
                                  int32_t ldo, void *stream, int32_t iters, float *ms_per_pass) {
+  if (int brc = BindThread()) return brc;
   if (!ms_per_pass || iters <= 0) return AMLIKE_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipEvent_t e0, e1;
