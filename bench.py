@@ -48,7 +48,7 @@ BF16X3_PRODUCTS = 6
 F16X2_PRODUCTS = 3
 
 
-def cpu_baseline_gmm(model, gconsts, dim, seconds_target=15.0):
+def cpu_baseline_gmm(model, gconsts, dim, seconds_target=30.0):
     """Times the reference CPU path on a bounded sample of the same workload."""
     import oracle
     from oracle import kaldi_io as kio
