@@ -121,6 +121,16 @@ __device__ __forceinline__ float scalar_bit_as_float(uint32_t mask, int bit) {
   return r;
 }
 
+// Waits for every outstanding vector-memory operation of this wave.  The feature tiles are
+// staged with global_load ... lds, whose arrival in LDS only the vector-memory counter tracks:
+// a wave must have seen its own staging loads complete before it enters the barrier that
+// publishes them (the compiler's barrier sequence does not wait on that counter by itself).
+__device__ __forceinline__ void wait_vector_memory() {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ bool guard_skips(const int *ctl, int fix_cap, int guard) {
   if (guard == 0) return false;
   const int range = __builtin_nontemporal_load(ctl + 1), count = __builtin_nontemporal_load(ctl);
@@ -495,6 +505,7 @@ __global__ void __launch_bounds__(64 * W, OCC)
   };
   if (ngroup > 0) stage(0);
   if (ngroup > 1) stage(1);
+  wait_vector_memory();
   __syncthreads();  // gconst visible; groups 0 and 1 landed (the barrier drains LDS-DMA)
   if (ntile == 0) return;
 
@@ -560,6 +571,7 @@ __global__ void __launch_bounds__(64 * W, OCC)
     // g+2 overwrite the buffer of group g.
     const int fn = ft + 1;
     if (fn % FTB == 0 && !(ABL & 16)) {
+      wait_vector_memory();
       __syncthreads();
       const int g = fn / FTB;
       if (g + 1 < ngroup) stage(g + 1);
@@ -723,6 +735,7 @@ __global__ void __launch_bounds__(64 * W, OCC)
   };
   if (ngroup > 0) stage(0);
   if (ngroup > 1) stage(1);
+  wait_vector_memory();
   __syncthreads();
   if (ntile == 0) return;
 
@@ -848,6 +861,10 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #if AMLIKE_DIFF_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
 #endif
+    // The next iteration opens with the barrier that publishes a staged group: see this wave's
+    // staging loads (issued FTB tiles ago) complete here, before this tile's stores join the
+    // queue, rather than at the barrier itself, where the wait would also cover those stores.
+    if ((ft + 2) % FTB == 0 && !(ABL & 16)) wait_vector_memory();
     // Loop over the segments of this wave's chunk, two per iteration: lanes 0-31 finish
     // segment 2k and lanes 32-63 segment 2k+1 of the same 32 frames.  One
     // v_permlane32_swap of (value for a, value for b) leaves, in each half-wave, that
