@@ -63,7 +63,9 @@ int amlike_host_free(void *ptr);
  *   gconsts[G], means_invvars[G x dim], inv_vars[G x dim]  (row-major, dense),
  *   pdf_offsets[num_pdfs + 1]: pdf j owns Gaussians [pdf_offsets[j], pdf_offsets[j+1]).
  * gconsts are the values DiagGmm::ComputeGconsts produces (gmm/diag-gmm.cc:114-152).
- * Host arrays are only read during the call; the handle owns a re-packed device copy. */
+ * Host arrays are only read during the call; the handle owns a re-packed device copy.
+ * Any dim: the fused kernels cover dim <= 64, larger ones go through the per-Gaussian score
+ * product and a log-sum-exp pass (same answers, lower rate). */
 int amlike_gmm_create(const float *gconsts, const float *means_invvars,
                       const float *inv_vars, const int32_t *pdf_offsets,
                       int32_t num_pdfs, int32_t num_gauss, int32_t dim,

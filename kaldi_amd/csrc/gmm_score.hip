@@ -1151,7 +1151,7 @@ __global__ void __launch_bounds__(256)
   float mx = -INFINITY;
   for (int g = g0; g < g1; ++g) mx = fmaxf(mx, row[g]);
   float cutoff = mx + (-15.9423847198486328125f);  // logf(FLT_EPSILON)
-  if (mx - prune > cutoff) cutoff = mx - prune;
+  if (prune > 0.0f && mx - prune > cutoff) cutoff = mx - prune;
   float sum = 0.0f;
   for (int g = g0; g < g1; ++g) {
     const float f = row[g];
@@ -1877,9 +1877,12 @@ int amlike_gmm_create(const float *gconsts, const float *means_invvars, const fl
     int rc = amlike_init(0);
     if (rc != AMLIKE_OK) return rc;
   }
-  const Variant *v = ChooseVariant(dim, true);  // PackModel may switch to the bf16x3 twin
-  if (!v) {
-    SetError("amlike_gmm_create: no kernel for feature dimension %d", dim);
+  // PackModel may switch to the bf16x3 twin.  Dimensions the fused kernels are not built for
+  // (above 64) have no variant: such a model is scored through the per-Gaussian score GEMM and
+  // a log-sum-exp pass over its result, which take any dimension.
+  const Variant *v = ChooseVariant(dim, true);
+  if (!v && (getenv("AMLIKE_GMM_MODE") || getenv("AMLIKE_GMM_VARIANT"))) {
+    SetError("amlike_gmm_create: no kernel for feature dimension %d with the requested mode", dim);
     return AMLIKE_EDIM;
   }
   amlike_gmm *g = new amlike_gmm;
@@ -1889,7 +1892,8 @@ int amlike_gmm_create(const float *gconsts, const float *means_invvars, const fl
   g->device = CurrentDevice();
   g->variant = v;
   g->pdf_offsets.assign(pdf_offsets, pdf_offsets + num_pdfs + 1);
-  int rc = PackModel(g, gconsts, means_invvars, inv_vars, pdf_offsets);
+  int rc = v ? PackModel(g, gconsts, means_invvars, inv_vars, pdf_offsets) : AMLIKE_OK;
+  if (!v) g->info = "per-Gaussian score GEMM + log-sum-exp pass (no fused kernel for this dimension)";
   if (rc == AMLIKE_OK) {
     auto up = [&](float **dst, const float *src, size_t n) -> int {
       AMLIKE_HIP(hipMalloc(dst, n * sizeof(float)));
@@ -1978,7 +1982,7 @@ int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32
   int rc = CheckScoreArgs(g, T, ld, feat_dim, ldo, d_feats, d_out);
   if (rc != AMLIKE_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (log_sum_exp_prune > 0.0f) {
+  if (log_sum_exp_prune > 0.0f || !g->variant) {
     // Pruning needs each pdf's maximum before its sum, so this mode goes through the
     // per-Gaussian scores, in frame chunks that bound the scratch matrix.
     const int G = g->num_gauss;
@@ -1999,7 +2003,7 @@ int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32
                          d_out + (size_t)t0 * ldo, ldo, g->d_flag);
       AMLIKE_HIP(hipGetLastError());
     }
-    g->info = "pruned log-sum-exp over per-Gaussian scores";
+    if (g->variant) g->info = "pruned log-sum-exp over per-Gaussian scores";
     return AMLIKE_OK;
   }
   const float *use = d_feats;
@@ -2219,7 +2223,8 @@ int amlike_gmm_gauss_loglikes_dev(amlike_gmm_t *g, int32_t pdf_begin, int32_t pd
     return AMLIKE_EINVAL;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (T >= 64 && g1 - g0 >= 64 && !getenv("AMLIKE_GMM_GAUSS_VALU")) {
+  const size_t valu_smem = (size_t)3 * 64 * (g->dim + 1) * sizeof(float);
+  if ((T >= 64 && g1 - g0 >= 64 && !getenv("AMLIKE_GMM_GAUSS_VALU")) || valu_smem > 64 * 1024) {
     // A [T x 2D] . [2D x M] product with the gconsts as bias: the bf16x3 matrix-instruction
     // GEMM of the nnet2 path, on plane images of the features (per call) and of the model
     // (once per handle).

@@ -443,3 +443,18 @@ def test_threads_sharing_one_handle_and_threads_with_their_own(amlike_device):
     assert len(results) == 6 * 2 * 5
     for (tag, i, rep), got in results.items():
         np.testing.assert_array_equal(got, want[i])
+
+
+@pytest.mark.parametrize("dim,P,G,T", [(100, 12, 150, 70), (72, 30, 300, 5), (117, 3, 10, 200)])
+def test_dimensions_beyond_the_fused_kernels(amlike_device, dim, P, G, T):
+    """Feature dimensions above 64 have no fused kernel; the model is scored through the
+    per-Gaussian score GEMM and a log-sum-exp pass, to the same tolerance."""
+    m = synth.make_gmm(dim, P, G, seed=400 + dim)
+    feats = synth.make_feats(m, T, seed=401)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    assert "no fused kernel" in am.kernel_info()
+    _check(m, feats, am.LogLikelihoods(feats))
+    comp = am.ComponentLogLikelihoods(feats[:3], 0, 2)
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    want = oracle.diag_gmm_loglikes_mat(gc, m["means_invvars"], m["inv_vars"], feats[:3])
+    assert np.abs(comp - want[:, :comp.shape[1]]).max() < TOL
