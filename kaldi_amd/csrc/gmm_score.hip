@@ -43,6 +43,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "amlike_common.h"
@@ -1408,6 +1409,22 @@ static bool ComputeF16Scales(const std::vector<double> &amax, const std::vector<
   return true;
 }
 
+// fn(i) for i in [0, n) on up to 16 host threads (contiguous ranges).
+template <typename F>
+static void ParallelFor(int n, F fn, int grain = 64) {
+  const int nt = std::max(1, std::min({16, (int)std::thread::hardware_concurrency(), n / grain}));
+  if (nt <= 1) {
+    for (int i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; ++t)
+    pool.emplace_back([=, &fn]() {
+      for (int i = (int)((long long)n * t / nt); i < (int)((long long)n * (t + 1) / nt); ++i) fn(i);
+    });
+  for (std::thread &th : pool) th.join();
+}
+
 static int Upload(void **dst, const void *src, size_t bytes) {
   AMLIKE_HIP(hipMalloc(dst, bytes));
   AMLIKE_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
@@ -1499,23 +1516,39 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
   if (f16) {
     std::vector<double> amax((size_t)2 * D, 0.0), xr(D, 0.0);
     bool ok = true;
-    for (const Piece &p : pieces) {
-      const int ref = order[p.g_begin];
-      for (int q = 0; q < p.count && ok; ++q) {
-        const int gi = order[p.g_begin + q];
-        if (!std::isfinite(gconsts[gi])) continue;
-        for (int d = 0; d < D; ++d) {
-          const double v = iv[(size_t)gi * D + d], m = miv[(size_t)gi * D + d];
-          if (!(v > 0.0) || !std::isfinite(v) || !std::isfinite(m)) {
-            ok = false;
-            break;
-          }
-          xr[d] = std::max(xr[d], std::fabs(m / v) + 8.0 / std::sqrt(v));
-          for (int kind = 0; kind < 2; ++kind) {
-            const float a = opval(gi, (want_diff && q > 0) ? ref : -1, kind, d);
-            amax[(size_t)kind * D + d] = std::max(amax[(size_t)kind * D + d], (double)std::fabs(a));
+    {
+      // per-range maxima on host threads, then reduced
+      const int nr = 16;
+      std::vector<std::vector<double>> pa(nr, std::vector<double>((size_t)2 * D, 0.0)),
+          px(nr, std::vector<double>(D, 0.0));
+      std::vector<char> pok(nr, 1);
+      ParallelFor(nr, [&](int t) {
+        std::vector<double> &am = pa[t], &xm = px[t];
+        for (size_t pi = pieces.size() * t / nr; pi < pieces.size() * (t + 1) / nr && pok[t]; ++pi) {
+          const Piece &p = pieces[pi];
+          const int ref = order[p.g_begin];
+          for (int q = 0; q < p.count && pok[t]; ++q) {
+            const int gi = order[p.g_begin + q];
+            if (!std::isfinite(gconsts[gi])) continue;
+            for (int d = 0; d < D; ++d) {
+              const double v = iv[(size_t)gi * D + d], m = miv[(size_t)gi * D + d];
+              if (!(v > 0.0) || !std::isfinite(v) || !std::isfinite(m)) {
+                pok[t] = 0;
+                break;
+              }
+              xm[d] = std::max(xm[d], std::fabs(m / v) + 8.0 / std::sqrt(v));
+              for (int kind = 0; kind < 2; ++kind) {
+                const float a = opval(gi, (want_diff && q > 0) ? ref : -1, kind, d);
+                am[(size_t)kind * D + d] = std::max(am[(size_t)kind * D + d], (double)std::fabs(a));
+              }
+            }
           }
         }
+      }, 1);
+      for (int t = 0; t < nr; ++t) {
+        ok = ok && pok[t];
+        for (size_t i = 0; i < amax.size(); ++i) amax[i] = std::max(amax[i], pa[t][i]);
+        for (int d = 0; d < D; ++d) xr[d] = std::max(xr[d], px[t][d]);
       }
     }
     ok = ok && ComputeF16Scales(amax, xr, D, KS, &ascale, &bscale);
@@ -1597,7 +1630,8 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
   if (kernel_image) gcpack_k.assign((size_t)num_wc * NT * 32, kPadGconst);
   std::vector<uint32_t> endmask((size_t)num_wc * NT, 0u);
   std::vector<int32_t> segcol((size_t)num_wc * NT * 16, kColDiscard);
-  for (int wc = 0; wc < num_wc; ++wc) {
+  // Every wave chunk fills its own stretch of the images: spread them over host threads.
+  ParallelFor(num_wc, [&](int wc) {
     int slot = 0, seg = 0;
     for (const Piece &p : chunks[wc]) {
       const int ref = order[p.g_begin];
@@ -1661,7 +1695,7 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
       }
       endmask[(size_t)wc * NT + NT - 1] |= 1u << 15;
     }
-  }
+  });
 
   int rc = AMLIKE_OK;
   if (vmode == 0) {

@@ -12,7 +12,10 @@ from kaldi_amd import _lib, gmm, synth
 D, P, G = synth.GMM_CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "swbd_tri4"]
 m = synth.make_gmm(D, P, G, seed=777)
 _lib.check(_lib.lib().amlike_init(0))
+import time
+t0 = time.perf_counter()
 am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+print("model packed and uploaded in %.3f s" % (time.perf_counter() - t0), flush=True)
 for T in (1, 32, 250, 500, 1000, 2000, 4000, 8000):
     feats = np.zeros((T, 40), np.float32)
     feats[:, :D] = synth.make_feats(m, T, seed=5)
