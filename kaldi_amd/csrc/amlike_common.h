@@ -34,6 +34,14 @@ struct DeviceBuffer {
   void Free();
 };
 
+// Copies a dense device matrix [rows x cols] (row stride cols) to host rows of stride ldo,
+// enqueued on `st` behind the kernels that produce it, and waits for it.  Page-locked
+// destinations get one asynchronous copy.  Ordinary (pageable) destinations -- what a caller
+// holding a plain malloc'ed matrix has -- go through page-locked staging buffers in 32 MB
+// chunks, the link copy of chunk i+1 and i+2 overlapping a multi-threaded host copy of chunk i:
+// about twice the rate of the runtime's own pageable path for results of a gigabyte.
+int CopyMatrixToHost(float *out, size_t ldo, const float *d_src, int rows, int cols, hipStream_t st);
+
 // One submission of the asynchronous host-pointer entry points (*_submit / *_wait): its own
 // device input and output buffers, the event the output copy waits for, the event the
 // caller waits for, and a pinned word the non-finite flag lands in.

@@ -1,7 +1,13 @@
 // Process-level state of libamlike: device binding, error text, buffers.
 #include "amlike_common.h"
 
+#include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 namespace amlike {
 
@@ -55,6 +61,147 @@ void DeviceBuffer::Free() {
   if (ptr) (void)hipFree(ptr);
   ptr = nullptr;
   bytes = 0;
+}
+
+namespace {
+
+// A few persistent host threads that split large memcpys between them.
+class HostCopyPool {
+ public:
+  static HostCopyPool &Get() {
+    static HostCopyPool pool;
+    return pool;
+  }
+  // dst[r * dpitch .. + width) = src[r * spitch .. + width) for r < rows (bytes), in parallel.
+  void Copy2D(char *dst, size_t dpitch, const char *src, size_t spitch, size_t width, size_t rows) {
+    const int parts = (int)std::min<size_t>(workers_.size() + 1, std::max<size_t>(1, rows * width >> 20));
+    if (parts <= 1) {
+      CopyRows(dst, dpitch, src, spitch, width, 0, rows);
+      return;
+    }
+    {
+      std::unique_lock<std::mutex> lock(mu_);
+      pending_ = parts - 1;
+      for (int p = 1; p < parts; ++p) {
+        const size_t r0 = rows * p / parts, r1 = rows * (p + 1) / parts;
+        tasks_.push_back([=]() { CopyRows(dst, dpitch, src, spitch, width, r0, r1); });
+      }
+    }
+    cv_.notify_all();
+    CopyRows(dst, dpitch, src, spitch, width, 0, rows / parts);  // the caller takes part 0
+    std::unique_lock<std::mutex> lock(mu_);
+    done_.wait(lock, [&]() { return pending_ == 0; });
+  }
+
+ private:
+  HostCopyPool() {
+    const int n = std::max(1, std::min(7, (int)std::thread::hardware_concurrency() / 2 - 1));
+    for (int i = 0; i < n; ++i) workers_.emplace_back([this]() { Work(); });
+  }
+  ~HostCopyPool() {
+    {
+      std::unique_lock<std::mutex> lock(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (std::thread &t : workers_) t.join();
+  }
+  static void CopyRows(char *dst, size_t dpitch, const char *src, size_t spitch, size_t width,
+                       size_t r0, size_t r1) {
+    if (dpitch == width && spitch == width) {
+      memcpy(dst + r0 * width, src + r0 * width, (r1 - r0) * width);
+      return;
+    }
+    for (size_t r = r0; r < r1; ++r) memcpy(dst + r * dpitch, src + r * spitch, width);
+  }
+  void Work() {
+    for (;;) {
+      std::function<void()> task;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&]() { return stop_ || !tasks_.empty(); });
+        if (stop_ && tasks_.empty()) return;
+        task = std::move(tasks_.back());
+        tasks_.pop_back();
+      }
+      task();
+      std::unique_lock<std::mutex> lock(mu_);
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::vector<std::function<void()>> tasks_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  int pending_ = 0;
+  bool stop_ = false;
+};
+
+constexpr size_t kStageBytes = (size_t)32 << 20;
+constexpr int kStageBuffers = 3;
+struct Staging {
+  std::mutex mu;  // one pipelined copy at a time per process
+  char *buf[kStageBuffers] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[kStageBuffers] = {nullptr, nullptr, nullptr};
+  int device = -1;
+};
+Staging g_staging;
+
+bool IsPageLocked(const void *p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
+}  // namespace
+
+int CopyMatrixToHost(float *out, size_t ldo, const float *d_src, int rows, int cols, hipStream_t st) {
+  const size_t row_bytes = (size_t)cols * sizeof(float), total = row_bytes * rows;
+  const bool staged = total >= 2 * kStageBytes && !IsPageLocked(out) && !getenv("AMLIKE_NO_STAGED_COPY");
+  if (!staged) {
+    if (ldo == (size_t)cols)
+      AMLIKE_HIP(hipMemcpyAsync(out, d_src, total, hipMemcpyDeviceToHost, st));
+    else
+      AMLIKE_HIP(hipMemcpy2DAsync(out, ldo * sizeof(float), d_src, row_bytes, row_bytes, rows,
+                                  hipMemcpyDeviceToHost, st));
+    AMLIKE_HIP(hipStreamSynchronize(st));
+    return AMLIKE_OK;
+  }
+  std::lock_guard<std::mutex> lock(g_staging.mu);
+  if (g_staging.device != g_device) {  // first use (one device per process)
+    for (int i = 0; i < kStageBuffers; ++i) {
+      AMLIKE_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_staging.buf[i]), kStageBytes, hipHostMallocDefault));
+      AMLIKE_HIP(hipEventCreateWithFlags(&g_staging.ev[i], hipEventDisableTiming));
+    }
+    g_staging.device = g_device;
+  }
+  const int chunk_rows = (int)std::max<size_t>(1, kStageBytes / row_bytes);
+  const int nchunks = (rows + chunk_rows - 1) / chunk_rows;
+  auto drain = [&](int c) -> int {
+    const int r0 = c * chunk_rows, rn = std::min(chunk_rows, rows - r0);
+    AMLIKE_HIP(hipEventSynchronize(g_staging.ev[c % kStageBuffers]));
+    HostCopyPool::Get().Copy2D(reinterpret_cast<char *>(out + (size_t)r0 * ldo), ldo * sizeof(float),
+                               g_staging.buf[c % kStageBuffers], row_bytes, row_bytes, (size_t)rn);
+    return AMLIKE_OK;
+  };
+  for (int c = 0; c < nchunks; ++c) {
+    const int r0 = c * chunk_rows, rn = std::min(chunk_rows, rows - r0);
+    AMLIKE_HIP(hipMemcpyAsync(g_staging.buf[c % kStageBuffers], d_src + (size_t)r0 * cols,
+                              (size_t)rn * row_bytes, hipMemcpyDeviceToHost, st));
+    AMLIKE_HIP(hipEventRecord(g_staging.ev[c % kStageBuffers], st));
+    if (c >= kStageBuffers - 1) {
+      int rc = drain(c - (kStageBuffers - 1));
+      if (rc != AMLIKE_OK) return rc;
+    }
+  }
+  for (int c = std::max(0, nchunks - (kStageBuffers - 1)); c < nchunks; ++c) {
+    int rc = drain(c);
+    if (rc != AMLIKE_OK) return rc;
+  }
+  return AMLIKE_OK;
 }
 
 int AsyncSlot::Prepare() {

@@ -2079,14 +2079,8 @@ static int ScoreResidentToHost(amlike_gmm *g, const float *df, int T, int dld, f
     float *dout = static_cast<float *>(g->ws_out.ptr);
     rc = amlike_gmm_score_dev(g, df + (size_t)t0 * dld, tn, dld, g->dim, prune, dout, P, g->stream);
     if (rc != AMLIKE_OK) return rc;
-    if (ldo == P) {
-      AMLIKE_HIP(hipMemcpyAsync(out + (size_t)t0 * ldo, dout, (size_t)tn * P * sizeof(float),
-                                hipMemcpyDeviceToHost, g->stream));
-    } else {
-      AMLIKE_HIP(hipMemcpy2DAsync(out + (size_t)t0 * ldo, (size_t)ldo * sizeof(float), dout,
-                                  (size_t)P * sizeof(float), (size_t)P * sizeof(float), tn,
-                                  hipMemcpyDeviceToHost, g->stream));
-    }
+    rc = CopyMatrixToHost(out + (size_t)t0 * ldo, (size_t)ldo, dout, tn, P, g->stream);
+    if (rc != AMLIKE_OK) return rc;
     rc = amlike_gmm_poll(g, g->stream);
     if (rc == AMLIKE_ENONFINITE) status = rc;
     else if (rc != AMLIKE_OK) return rc;

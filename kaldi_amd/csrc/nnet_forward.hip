@@ -1730,16 +1730,7 @@ int amlike_nnet_compute(amlike_nnet_t *n, const float *feats, int32_t T, int32_t
   rc = amlike_nnet_compute_dev(n, din, T, dld, pad_input, mode, prob_scale, dout,
                                n->output_dim, n->stream);
   if (rc != AMLIKE_OK) return rc;
-  if (ldo == n->output_dim)
-    AMLIKE_HIP(hipMemcpyAsync(out, dout, (size_t)t_out * n->output_dim * sizeof(float),
-                              hipMemcpyDeviceToHost, n->stream));
-  else
-    AMLIKE_HIP(hipMemcpy2DAsync(out, (size_t)ldo * sizeof(float), dout,
-                                (size_t)n->output_dim * sizeof(float),
-                                (size_t)n->output_dim * sizeof(float), t_out, hipMemcpyDeviceToHost,
-                                n->stream));
-  AMLIKE_HIP(hipStreamSynchronize(n->stream));
-  return AMLIKE_OK;
+  return CopyMatrixToHost(out, (size_t)ldo, dout, t_out, n->output_dim, n->stream);
 }
 
 int amlike_nnet_compute_submit(amlike_nnet_t *n, const float *feats, int32_t T, int32_t ld,
