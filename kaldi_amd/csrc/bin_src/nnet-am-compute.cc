@@ -1,6 +1,7 @@
 // nnet-am-compute on MI355X: same command line, inputs and outputs as the reference
 // binary (/root/reference/src/nnet2bin/nnet-am-compute.cc:27-110); NnetComputation()
 // (:91) and the optional floor + log (:93-96) run on the GPU through libamlike.
+#include <chrono>
 #include <iostream>
 #include <string>
 
@@ -55,6 +56,8 @@ int main(int argc, char *argv[]) {
     const int mode = divide_by_priors ? AMLIKE_NNET_LOGLIKES : apply_log ? AMLIKE_NNET_LOG : AMLIKE_NNET_POSTERIORS;
     // Two utterances in flight: reading utterance k+1 and writing utterance k-1 overlap the
     // GPU's work on utterance k.
+    am_nnet.Engine();  // weight images built and uploaded before the clock starts
+    const auto t0 = std::chrono::steady_clock::now();
     LikelihoodPipeline pipe(am_nnet, pad_input, mode, prob_scale);
     auto drain_one = [&]() {
       std::string utt;
@@ -78,6 +81,9 @@ int main(int argc, char *argv[]) {
       num_frames += feats.NumRows();
     }
     while (!pipe.Empty()) drain_one();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cerr << "LOG (nnet-am-compute) " << num_frames << " frames in " << secs << " s ("
+              << (secs > 0 ? num_frames / secs : 0.0) << " frames/s including file I/O)\n";
     std::cerr << "LOG (nnet-am-compute) Processed " << num_done << " feature files, " << num_frames
               << " frames of input were processed.\n";
     return (num_done == 0 ? 1 : 0);

@@ -95,6 +95,21 @@ def main():
                            capture_output=True, timeout=600)
         for line in p.stderr.decode().strip().splitlines()[-2:]:
             print("gmm-compute-likes x4:", line, flush=True)
+        # 5. nnet-am-compute on the swbd-sized p-norm net, same utterances (40-dim input)
+        comps, priors = synth.make_pnorm_nnet(seed=780)
+        with kio.open_out(os.path.join(d, "nnet.mdl"), True) as f:
+            topo, triples = kio.make_transition_model(len(priors))
+            kio.write_transition_model(f, True, topo, triples)
+            kio.write_am_nnet(f, True, comps, priors)
+        rng = np.random.default_rng(3)
+        nitems = [("utt%03d" % i, rng.standard_normal((int(n_), 40)).astype(np.float32)) for i, n_ in enumerate(lens)]
+        kio.write_ark(os.path.join(d, "nfeats.ark"), nitems * 4)
+        t0 = time.perf_counter()
+        p = subprocess.run([os.path.join(BIN, "nnet-am-compute"), "--apply-log=true", os.path.join(d, "nnet.mdl"),
+                            "ark:" + os.path.join(d, "nfeats.ark"), "ark:/dev/null"], capture_output=True, timeout=600)
+        dt = time.perf_counter() - t0
+        print("nnet-am-compute x4:", " | ".join(p.stderr.decode().strip().splitlines()[-2:]),
+              "| whole process %.2f s = %.0f frames/s" % (dt, 4 * T / dt), flush=True)
     finally:
         import shutil
         shutil.rmtree(d, ignore_errors=True)
