@@ -2436,7 +2436,11 @@ int amlike_gmm_time_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, 
   AMLIKE_HIP(hipEventRecord(e0, st));
   for (int i = 0; i < iters; ++i) {
     int rc = amlike_gmm_score_dev(g, d_feats, T, ld, feat_dim, -1.0f, d_out, ldo, stream);
-    if (rc != AMLIKE_OK) return rc;
+    if (rc != AMLIKE_OK) {
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      return rc;
+    }
   }
   AMLIKE_HIP(hipEventRecord(e1, st));
   AMLIKE_HIP(hipEventSynchronize(e1));

@@ -1834,7 +1834,11 @@ int amlike_nnet_time_compute_dev(amlike_nnet_t *n, const float *d_feats, int32_t
   AMLIKE_HIP(hipEventRecord(e0, st));
   for (int i = 0; i < iters; ++i) {
     int rc = amlike_nnet_compute_dev(n, d_feats, T, ld, pad_input, mode, prob_scale, d_out, ldo, stream);
-    if (rc != AMLIKE_OK) return rc;
+    if (rc != AMLIKE_OK) {
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      return rc;
+    }
   }
   AMLIKE_HIP(hipEventRecord(e1, st));
   AMLIKE_HIP(hipEventSynchronize(e1));
