@@ -458,3 +458,36 @@ def test_dimensions_beyond_the_fused_kernels(amlike_device, dim, P, G, T):
     gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
     want = oracle.diag_gmm_loglikes_mat(gc, m["means_invvars"], m["inv_vars"], feats[:3])
     assert np.abs(comp - want[:, :comp.shape[1]]).max() < TOL
+
+
+def test_like_the_reference_unit_test_of_diag_gmm(amlike_device):
+    """The reference's own check (gmm/diag-gmm-test.cc:86-141): for small random mixtures
+    (1-10 dimensions, 1-10 components) the log-likelihood equals the log-sum of the component
+    densities written out from first principles; and (gmm/am-diag-gmm-test.cc:32-72) a pdf
+    scored inside an acoustic model equals the same mixture scored on its own."""
+    rng = np.random.default_rng(2024)
+    for trial in range(25):
+        dim, nmix = int(rng.integers(1, 11)), int(rng.integers(1, 11))
+        feat = rng.standard_normal(dim)
+        means = rng.standard_normal((nmix, dim))
+        var = np.exp(rng.standard_normal((nmix, dim))) + 1e-5
+        w = rng.uniform(size=nmix)
+        w /= w.sum()
+        comp = np.log(w) - 0.5 * (np.log(2 * np.pi) + np.log(var) + (feat - means) ** 2 / var).sum(1)
+        loglike = np.logaddexp.reduce(comp)
+        iv = (1.0 / var).astype(np.float32)
+        miv = (means / var).astype(np.float32)
+        one = gmm.AmDiagGmm(w.astype(np.float32), miv, iv, np.array([0, nmix], np.int32))
+        got = one.LogLikelihoods(feat[None, :].astype(np.float32))[0, 0]
+        assert abs(got - loglike) <= 1e-3 * max(1.0, abs(loglike)), (trial, got, loglike)
+        per = one.ComponentLogLikelihoods(feat[None, :].astype(np.float32))[0]
+        assert np.abs(per - comp).max() <= 1e-3 * max(1.0, np.abs(comp).max())
+        # the same mixture as pdf 1 of a three-pdf model
+        other = synth.make_gmm(dim, 2, 6, seed=trial)
+        am3 = gmm.AmDiagGmm(
+            np.concatenate([other["weights"][:3], w.astype(np.float32), other["weights"][3:]]),
+            np.concatenate([other["means_invvars"][:3], miv, other["means_invvars"][3:]]),
+            np.concatenate([other["inv_vars"][:3], iv, other["inv_vars"][3:]]),
+            np.array([0, 3, 3 + nmix, 6 + nmix], np.int32))
+        got3 = am3.LogLikelihoods(feat[None, :].astype(np.float32))[0, 1]
+        assert abs(got3 - got) <= 2e-4 * max(1.0, abs(loglike))
