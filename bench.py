@@ -6,7 +6,8 @@ second figure on the same line, of the nnet2 p-norm forward) on MI355X.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of the hot path over one batch: the rank's shard of synthetic
-utterances (lengths ~U[200,1500], concatenated frame-wise, resident in HBM)
+utterances (256 per GPU, the benchmark definition's 2048 utterances over 8 GPUs; lengths
+~U[200,1500], about 218 k frames, concatenated frame-wise, resident in HBM)
 scored against the swbd-tri4-shaped GMM (D=40, 8600 pdfs, 200000 Gaussians),
 dense [T x 8600] log-likelihoods left in HBM.  Utterances are sharded over
 ranks (one process per GPU, the reference's JOB=1:$nj practice); there is no
@@ -46,6 +47,9 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (v_mfma_f32_32x3
 BF16X3_PRODUCTS = 6
 # The default kernel uses fp16x2 operands (same matrix rate as bf16): 3 partial products.
 F16X2_PRODUCTS = 3
+# rocprofv3 --pmc passes over the scoring kernel on the default workload (frames on rank 0 at
+# N = 1), KB per launch: profiles/r1_i_gmm_diff_pmc_summary.txt
+PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 3246530.0, 8875470.0
 
 
 def cpu_baseline_gmm(model, gconsts, dim, seconds_target=30.0):
@@ -85,7 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="swbd_tri4", choices=sorted(synth.GMM_CONFIGS))
-    ap.add_argument("--utts-per-gpu", type=int, default=40)
+    ap.add_argument("--utts-per-gpu", type=int, default=256)  # 2048 utterances over 8 GPUs
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nnet", action="store_true")
     args = ap.parse_args()
@@ -170,11 +174,11 @@ def main():
     # gfx950 correction for 16-byte-per-lane loads).  Only valid for that kernel and shape.
     traffic = traffic_detail = None
     if args.config == "swbd_tri4" and "gmm_score_diff_kernel<5,2,8,2,f16x2>" in am.kernel_info() \
-            and T == 35554:
-        traffic = 2.0 * 611329e3 + 1324680e3
-        traffic_detail = {"fetch_bytes": 2.0 * 611329e3, "write_bytes": 1324680e3,
+            and T == PMC_FRAMES:
+        traffic = 2.0 * PMC_FETCH_KB * 1e3 + PMC_WRITE_KB * 1e3
+        traffic_detail = {"fetch_bytes": 2.0 * PMC_FETCH_KB * 1e3, "write_bytes": PMC_WRITE_KB * 1e3,
                           "algorithmic_bytes": 4.0 * T * P + 4.0 * T * D,
-                          "source": "profiles/r1_g_gmm_diff_pmc_summary.txt"}
+                          "source": "profiles/r1_i_gmm_diff_pmc_summary.txt"}
 
     if rank == 0:
         value = tot_frames * args.steps / elapsed
