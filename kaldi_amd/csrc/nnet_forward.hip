@@ -748,6 +748,63 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// NormalizeComponent whose result only feeds an affine stage on fp16x2 operands: the scaled
+// rows are written straight as that stage's operand planes (k-octet-major, zero padded to Kp,
+// 1.0 in column one_col when the consumer carries its bias as a k column), and the fp32 copy
+// plus the separate split pass disappear.  One block = RB consecutive rows, brought into LDS
+// with coalesced loads (row stride odd, so a thread walking one row meets no bank conflict);
+// then one scale per row from 256 / RB partial sums, then thread (row, octet) work with the rows
+// of an octet contiguous in the output, as in nnet_split_planes_kernel.
+template <int RB>
+__global__ void __launch_bounds__(256)
+    nnet_normalize_planes_kernel(const float *__restrict__ in, int ld_in, int dim, int rows,
+                                 Planes out, int one_col) {
+  constexpr int NQ = 256 / RB;  // threads per row
+  extern __shared__ float s_norm[];
+  const int dimp = dim | 1;
+  float *s_x = s_norm;              // [RB][dimp]
+  float *s_p = s_norm + RB * dimp;  // [NQ][RB] partial sums, then [RB] scales
+  const int r0 = blockIdx.x * RB;
+  const int nrow = min(RB, rows - r0);
+  for (int i = threadIdx.x; i < nrow * dim; i += 256) {
+    const int rr = i / dim, c = i - rr * dim;
+    s_x[rr * dimp + c] = in[(size_t)(r0 + rr) * ld_in + c];
+  }
+  __syncthreads();
+  const int rr = threadIdx.x % RB, q = threadIdx.x / RB;
+  {
+    float ss = 0.0f;
+    if (rr < nrow)
+      for (int c = q; c < dim; c += NQ) ss += s_x[rr * dimp + c] * s_x[rr * dimp + c];
+    s_p[q * RB + rr] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x < RB) {
+    float ss = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) ss += s_p[k * RB + threadIdx.x];
+    s_p[threadIdx.x] = 1.0f / sqrtf(fmaxf(ss / dim, 1.3552527156068805e-20f));
+  }
+  __syncthreads();
+  if (rr >= nrow) return;
+  const float f = s_p[rr];
+  const int kp8 = out.Kp >> 3;
+  uint4 *o = reinterpret_cast<uint4 *>(out.p);
+  const size_t pstride = out.stride >> 3;
+  const float *x = s_x + rr * dimp;
+  for (int oct = q; oct < kp8; oct += NQ) {
+    const int c0 = oct * 8;
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = c0 + j < dim ? x[c0 + j] * f : (c0 + j == one_col ? 1.0f : 0.0f);
+    uint4 s0, s1;
+    split_f16x2_8(make_float4(t[0], t[1], t[2], t[3]), make_float4(t[4], t[5], t[6], t[7]), s0, s1);
+    const size_t i = (size_t)oct * rows + (r0 + rr);
+    o[i] = s0;
+    o[pstride + i] = s1;
+  }
+}
+
 // mode bits for the fused output post-processing.
 constexpr int kPostFloorLog = 1;  // max(v, 1e-20) then log
 constexpr int kPostPrior = 2;     // minus log prior, times scale
@@ -1219,6 +1276,9 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
     cur_rows = gather_rows[gi++];
     which ^= 1;
   }
+  // Set when the previous stage has already written this stage's operand planes into ws_planes
+  // (nnet_normalize_planes_kernel): the split pass is then skipped.
+  bool planes_ready = false;
   for (size_t si = 0; si < ns; ++si) {
     const Stage &s = n->stages[si];
     const bool last = (si + 1 == ns);
@@ -1288,15 +1348,40 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         AMLIKE_HIP(hipGetLastError());
         fused(0, pbase + 2 * pstride, s.d_wpn_safe, 2);
       } else {
-        split(s.f16, pbase, 0);
+        if (!planes_ready) split(s.f16, pbase, 0);
         AMLIKE_HIP(hipGetLastError());
         fused(s.f16, pbase, s.d_wpn, 0);
       }
+      planes_ready = false;
 #undef AMLIKE_PNORM_LAUNCH
       AMLIKE_HIP(hipGetLastError());
       float *fin = pdst;
       int fin_ld = pld;
-      if (norm) {
+      // The consumer of the normalised rows, when it is an affine stage on unconditional
+      // fp16x2 operands read from planes: write its planes directly.
+      const Stage *cons = (norm && si + 2 < ns) ? &n->stages[si + 2] : nullptr;
+      const bool direct = cons && cons->kind == AMLIKE_AFFINE && cons->f16 == 1 && cons->in_dim == G &&
+                          G <= 480 && !n->gemm_f32 && !n->gemm_inline_split && !getenv("AMLIKE_NNET_NO_DIRECT_PLANES");
+      if (direct) {
+        const bool cons_fused = cons->fuse_gs && si + 3 < ns;
+        const int ckp = cons_fused ? cons->Kpn : cons->Kp;
+        const size_t cstride = (size_t)cur_rows * ckp;
+        rc = n->ws_planes.Reserve(3 * cstride * sizeof(unsigned short));  // what the consumer asks for
+        if (rc != AMLIKE_OK) return rc;
+        Planes cp{static_cast<unsigned short *>(n->ws_planes.ptr), cstride, ckp};
+        const int rb = G <= 240 ? 64 : 32;
+        const size_t nsmem = ((size_t)rb * (G | 1) + 256) * sizeof(float);
+        if (rb == 64)
+          hipLaunchKernelGGL(nnet_normalize_planes_kernel<64>, dim3((unsigned)((cur_rows + 63) / 64)), dim3(256),
+                             nsmem, st, pdst, pld, G, (int)cur_rows, cp, cons_fused ? cons->in_dim : -1);
+        else
+          hipLaunchKernelGGL(nnet_normalize_planes_kernel<32>, dim3((unsigned)((cur_rows + 31) / 32)), dim3(256),
+                             nsmem, st, pdst, pld, G, (int)cur_rows, cp, cons_fused ? cons->in_dim : -1);
+        AMLIKE_HIP(hipGetLastError());
+        planes_ready = true;
+        fin = nullptr;  // no fp32 copy exists
+        fin_ld = RoundUp(G, 16);
+      } else if (norm) {
         fin = pn_last ? d_out : bufs[which ^ 1];
         fin_ld = pn_last ? ldo : RoundUp(G, 16);
         const int blocks = (int)std::min<int64_t>((cur_rows + 3) / 4, 8192);
@@ -1345,8 +1430,9 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
           const uint4 *x4 = reinterpret_cast<const uint4 *>(xpl);
           const size_t wplane = (size_t)s.out_dim * (s.Kp / 8);
           if (prec) {
-            hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
-                               s.in_dim, (int)cur_rows, xp, -1, flag, gmode);
+            if (!planes_ready)
+              hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                                 s.in_dim, (int)cur_rows, xp, -1, flag, gmode);
             hipLaunchKernelGGL((big_out ? nnet_gemm_bias_planes_kernel<1, true> : nnet_gemm_bias_planes_kernel<1, false>),
                                grid, dim3(256), 0, st, x4, pstride / 8, wpo, wplane, (size_t)s.out_dim, s.Kp,
                                s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim, flag, gmode);
@@ -1365,6 +1451,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         } else {
           split_gemm(s.f16, pbase, s.d_wpo, 0);
         }
+        planes_ready = false;
       }
       AMLIKE_HIP(hipGetLastError());
       if (!last && dst_ld != s.out_dim) {

@@ -195,3 +195,18 @@ def test_fp16_operands_on_trial_fall_back_when_the_input_does_not_fit(amlike_dev
     a, b = trial.Compute(x_nan), plain.Compute(x_nan)
     assert np.isnan(a[:10]).any()
     np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+
+
+@pytest.mark.parametrize("name", ["small", "mid", "mixup"])
+def test_normalised_rows_written_straight_as_operand_planes(amlike_device, name, monkeypatch):
+    """A NormalizeComponent that only feeds an fp16x2 affine stage writes that stage's operand
+    planes itself; the answers must agree with the two-pass route (fp32 rows, then the split
+    pass) to the last few bits (the row's sum of squares is added up in another order)."""
+    comps, priors = _nets()[name]
+    x = np.random.default_rng(123).normal(size=(333, comps[0]["input_dim"])).astype(np.float32)
+    direct = nnet.AmNnet(comps, priors).Compute(x, mode=nnet.LOGLIKES)
+    monkeypatch.setenv("AMLIKE_NNET_NO_DIRECT_PLANES", "1")
+    two_pass = nnet.AmNnet(comps, priors).Compute(x, mode=nnet.LOGLIKES)
+    np.testing.assert_allclose(direct, two_pass, rtol=2e-5, atol=2e-5)
+    want = oracle.nnet_compute(comps, priors, x, True, nnet.LOGLIKES, 1.0)
+    assert np.abs(direct - want).max() < 1e-3
