@@ -410,6 +410,107 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// SpliceComponent (with the edge padding of the first one) whose result only feeds an affine
+// stage: the gathered rows are written straight as that stage's operand planes, in the layout
+// of nnet_split_planes_kernel and with its range check / guard; the fp32 spliced matrix and
+// the separate split pass disappear.  Element semantics as in nnet_pad_splice_kernel.
+constexpr int kSpliceStageRows = 112;  // input rows a block of 64 output rows may stage
+template <int PREC>
+__global__ void __launch_bounds__(256)
+    nnet_splice_planes_kernel(const float *__restrict__ in, int ld_in, const UttMap *__restrict__ utts,
+                              int num_utts, int left_pad, int ns, int dim, int out_dim, int total_rows,
+                              Planes out, int one_col, int *flag, int gmode) {
+  if (gmode == 2 && nnet_guard_skips(flag, 2)) return;
+  // One block = 64 consecutive output rows.  Their source rows form one short stretch of the
+  // (back to back) input, which is brought into LDS with coalesced loads; thread (row, octet)
+  // then assembles its 8 values from LDS.  in_dim = dim + const tail.
+  extern __shared__ float s_spl[];
+  __shared__ int s_src0[64], s_rows[64];
+  const int in_dim = dim + (out_dim - ns * dim);
+  const int indp = in_dim | 1;
+  const int g0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int g = g0 + lane;
+  UttMap um = utts[0];
+  int r = 0;
+  if (g < total_rows) {
+    int lo = 0, hi = num_utts;  // the utterance output row g belongs to
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (utts[mid].out_off <= g) lo = mid; else hi = mid;
+    }
+    um = utts[lo];
+    r = g - um.out_off;
+  }
+  // first and last input row this block needs (rows of the block are in increasing order)
+  const int my_first = um.in_off + min(max(r - left_pad, 0), um.in_rows - 1);
+  const int my_last = um.in_off + min(max(r - left_pad + ns - 1, 0), um.in_rows - 1);
+  if (q == 0) {
+    s_src0[lane] = g < total_rows ? my_first : 0x7fffffff;
+    s_rows[lane] = g < total_rows ? my_last : -1;
+  }
+  __syncthreads();
+  int first = 0x7fffffff, last = -1;
+  for (int k = 0; k < 64; ++k) {
+    first = min(first, s_src0[k]);
+    last = max(last, s_rows[k]);
+  }
+  const int nstage = last - first + 1;
+  const bool staged = nstage <= kSpliceStageRows;
+  if (staged) {
+    for (int i = threadIdx.x; i < nstage * in_dim; i += 256) {
+      const int rr = i / in_dim, c = i - rr * in_dim;
+      s_spl[rr * indp + c] = in[(size_t)(first + rr) * ld_in + c];
+    }
+  }
+  __syncthreads();
+  if (g >= total_rows) return;
+  const int kp8 = out.Kp >> 3;
+  uint4 *o = reinterpret_cast<uint4 *>(out.p);
+  const size_t pstride = out.stride >> 3;
+  for (int oct = q; oct < kp8; oct += 4) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = oct * 8 + j;
+      float v = 0.0f;
+      int src = -1, d = 0;
+      if (c < ns * dim) {
+        const int k = c / dim;
+        d = c - k * dim;
+        src = um.in_off + min(max(r - left_pad + k, 0), um.in_rows - 1);
+      } else if (c < out_dim) {
+        d = dim + (c - ns * dim);
+        src = um.in_off + min(max(r - left_pad, 0), um.in_rows - 1);
+      } else if (c == one_col) {
+        v = 1.0f;
+      }
+      if (src >= 0) v = staged ? s_spl[(src - first) * indp + d] : in[(size_t)src * ld_in + d];
+      t[j] = v;
+    }
+    const float4 lo4 = make_float4(t[0], t[1], t[2], t[3]), hi4 = make_float4(t[4], t[5], t[6], t[7]);
+    const size_t i = (size_t)oct * total_rows + g;
+    if (PREC) {
+      if (gmode == 1) {
+        bool fits = true;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fits &= fabsf(t[j]) <= 32768.0f;  // false for NaN too
+        if (!fits) atomicOr(flag, 1);
+      }
+      uint4 s0, s1;
+      split_f16x2_8(lo4, hi4, s0, s1);
+      o[i] = s0;
+      o[pstride + i] = s1;
+    } else {
+      uint4 s0, s1, s2;
+      split_bf16x3_8(lo4, hi4, s0, s1, s2);
+      o[i] = s0;
+      o[pstride + i] = s1;
+      o[2 * pstride + i] = s2;
+    }
+  }
+}
+
 // The bf16x3 GEMM with both operands given as k-octet-major planes (X: [3][Kp/8][M], W:
 // [3][Kp/8][N] 16-byte elements): same tiling and LDS image as nnet_gemm_bias_bf16x3_kernel
 // (block tile 128 x 128, three blocks per CU), but both operand tiles are plain, fully
@@ -1278,7 +1379,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
   }
   // Set when the previous stage has already written this stage's operand planes into ws_planes
   // (nnet_normalize_planes_kernel): the split pass is then skipped.
-  bool planes_ready = false;
+  int planes_ready = 0;
   for (size_t si = 0; si < ns; ++si) {
     const Stage &s = n->stages[si];
     const bool last = (si + 1 == ns);
@@ -1290,6 +1391,50 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
     if (s.kind == AMLIKE_SPLICE) {
       // The gather kernel writes whole rows of dst_ld floats; on the last stage it must
       // stay inside out_dim.
+      const Stage *cons = !last ? &n->stages[si + 1] : nullptr;
+      const bool direct = cons && cons->kind == AMLIKE_AFFINE && cons->in_dim == s.out_dim &&
+                          (size_t)kSpliceStageRows * (s.in_dim | 1) * sizeof(float) <= 60 * 1024 && !n->gemm_f32 && !n->gemm_inline_split && !getenv("AMLIKE_NNET_NO_DIRECT_PLANES");
+      if (direct) {
+        // the spliced rows go straight into the consumer's operand planes
+        const bool cons_fused = cons->fuse_gs && si + 2 < ns;
+        const int ckp = cons_fused ? cons->Kpn : cons->Kp;
+        const int64_t total = gather_rows[gi];
+        const size_t cstride = (size_t)total * ckp;
+        rc = n->ws_planes.Reserve((cons->f16 == 2 ? 5 : 3) * cstride * sizeof(unsigned short));
+        if (rc != AMLIKE_OK) return rc;
+        unsigned short *pbase = static_cast<unsigned short *>(n->ws_planes.ptr);
+        int *flag = n->d_flags + si + 1;
+        const int one_col = cons_fused ? cons->in_dim : -1;
+        const int sblocks = (int)((total + 63) / 64);
+        const size_t ssmem = (size_t)kSpliceStageRows * (s.in_dim | 1) * sizeof(float);
+        const int lp = padded ? 0 : pad_l, nspl = s.left + s.right + 1, sdim = s.in_dim - s.const_dim;
+        auto splice_to = [&](int prec, unsigned short *dstp, int gmode) {
+          Planes xp{dstp, cstride, ckp};
+          if (prec)
+            hipLaunchKernelGGL(nnet_splice_planes_kernel<1>, dim3(sblocks), dim3(256), ssmem, st, cur, cur_ld,
+                               d_maps + gi * num_utts, num_utts, lp, nspl, sdim, s.out_dim, (int)total, xp,
+                               one_col, flag, gmode);
+          else
+            hipLaunchKernelGGL(nnet_splice_planes_kernel<0>, dim3(sblocks), dim3(256), ssmem, st, cur, cur_ld,
+                               d_maps + gi * num_utts, num_utts, lp, nspl, sdim, s.out_dim, (int)total, xp,
+                               one_col, flag, gmode);
+        };
+        if (cons->f16 == 2) {
+          splice_to(1, pbase, 1);
+          AMLIKE_HIP(hipGetLastError());
+          splice_to(0, pbase + 2 * cstride, 2);
+        } else {
+          splice_to(cons->f16, pbase, 0);
+        }
+        AMLIKE_HIP(hipGetLastError());
+        planes_ready = 2;
+        out_rows = gather_rows[gi++];
+        padded = true;
+        cur = nullptr;  // no fp32 copy exists
+        cur_ld = dst_ld;
+        cur_rows = out_rows;
+        continue;
+      }
       rc = launch_gather(padded ? 0 : pad_l, s.left + s.right + 1, s.in_dim - s.const_dim,
                          s.const_dim, dst, last ? s.out_dim : dst_ld, s.out_dim);
       if (rc != AMLIKE_OK) return rc;
@@ -1312,6 +1457,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       int *flag = n->d_flags + si;
       const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
       auto split = [&](int prec, unsigned short *dstp, int gmode) {
+        if (planes_ready) return;  // the producing stage has written them
         Planes xp{dstp, pstride, s.Kpn};
         if (prec)
           hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
@@ -1348,11 +1494,11 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         AMLIKE_HIP(hipGetLastError());
         fused(0, pbase + 2 * pstride, s.d_wpn_safe, 2);
       } else {
-        if (!planes_ready) split(s.f16, pbase, 0);
+        split(s.f16, pbase, 0);
         AMLIKE_HIP(hipGetLastError());
         fused(s.f16, pbase, s.d_wpn, 0);
       }
-      planes_ready = false;
+      planes_ready = 0;
 #undef AMLIKE_PNORM_LAUNCH
       AMLIKE_HIP(hipGetLastError());
       float *fin = pdst;
@@ -1378,7 +1524,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
           hipLaunchKernelGGL(nnet_normalize_planes_kernel<32>, dim3((unsigned)((cur_rows + 31) / 32)), dim3(256),
                              nsmem, st, pdst, pld, G, (int)cur_rows, cp, cons_fused ? cons->in_dim : -1);
         AMLIKE_HIP(hipGetLastError());
-        planes_ready = true;
+        planes_ready = 1;
         fin = nullptr;  // no fp32 copy exists
         fin_ld = RoundUp(G, 16);
       } else if (norm) {
@@ -1437,8 +1583,9 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
                                grid, dim3(256), 0, st, x4, pstride / 8, wpo, wplane, (size_t)s.out_dim, s.Kp,
                                s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim, flag, gmode);
           } else {
-            hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
-                               s.in_dim, (int)cur_rows, xp, -1, flag, gmode);
+            if (!planes_ready)
+              hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld,
+                                 s.in_dim, (int)cur_rows, xp, -1, flag, gmode);
             hipLaunchKernelGGL((big_out ? nnet_gemm_bias_planes_kernel<0, true> : nnet_gemm_bias_planes_kernel<0, false>),
                                grid, dim3(256), 0, st, x4, pstride / 8, wpo, wplane, (size_t)s.out_dim, s.Kp,
                                s.d_bias, dst, dst_ld, (int)cur_rows, s.out_dim, flag, gmode);
@@ -1451,7 +1598,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         } else {
           split_gemm(s.f16, pbase, s.d_wpo, 0);
         }
-        planes_ready = false;
+        planes_ready = 0;
       }
       AMLIKE_HIP(hipGetLastError());
       if (!last && dst_ld != s.out_dim) {
