@@ -22,7 +22,9 @@ The line also carries
                 takes (3 for the default fp16x2 operands); traffic = HBM bytes per launch from
                 rocprofv3 PMC passes of the same workload;
   cpu_baseline  the real reference library (oracle/_ref, kind "reference") or the
-                C restatement (kind "port") timed on a bounded sample, rank 0, N=1.
+                C restatement (kind "port") timed on a bounded sample, rank 0, N=1: one thread
+                (value, cores = 1) and, under all_cores, one single-threaded process per host
+                core of this job's share side by side; the nnet2 leg carries its own.
 """
 import argparse
 import json
@@ -52,35 +54,102 @@ F16X2_PRODUCTS = 3
 PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 3246530.0, 8875470.0
 
 
+def _cpu_workers():
+    """Worker processes for the all-cores figure: this process's share of the host, 16 at most."""
+    return max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16))
+
+
+def _ref_rates(oracle, make_args, items_for, n, workers):
+    """Times the real reference library (oracle/_ref) on n frames in one single-threaded process,
+    then in `workers` such processes side by side, n frames each (JOB=1:$nj).  Returns
+    (frames/s with one process, its seconds, frames/s with all workers, their slowest seconds)."""
+    from oracle import kaldi_io as kio
+    with tempfile.TemporaryDirectory() as d:
+        arg_lists = []
+        for w in range(workers):
+            fpath = os.path.join(d, "feats%d.ark" % w)
+            kio.write_ark(fpath, items_for(w))
+            arg_lists.append(make_args(d, "ark:" + fpath))
+        # untimed first run on a few frames: the BLAS library's start-up lands in its first call
+        kio.write_ark(os.path.join(d, "warm.ark"), [(k, v[:8]) for k, v in items_for(0)[:1]])
+        oracle.ref_driver(*make_args(d, "ark:" + os.path.join(d, "warm.ark")))
+        secs1 = float(oracle.ref_driver(*arg_lists[0]).split()[1])
+        if workers > 1:
+            secs_all = max(float(o.split()[1]) for o in oracle.ref_driver_many(arg_lists))
+        else:
+            secs_all = secs1
+    return n / secs1, secs1, workers * n / secs_all, secs_all
+
+
 def cpu_baseline_gmm(model, gconsts, dim, seconds_target=30.0):
     """Times the reference CPU path on a bounded sample of the same workload."""
     import oracle
     from oracle import kaldi_io as kio
     est_fps = 86.0 * 200000.0 / float(model["pdf_offsets"][-1])  # 1-thread reference on C3: 86 frames/s
-    n = int(max(32, min(4000, seconds_target * est_fps)))
-    feats = synth.make_feats(model, n, seed=778)
+    n = int(max(32, min(200000, seconds_target * est_fps)))
     if oracle.have_ref():
+        workers = _cpu_workers()
         off = model["pdf_offsets"]
         pdfs = [dict(weights=model["weights"][off[j]:off[j + 1]],
                      means_invvars=model["means_invvars"][off[j]:off[j + 1]],
                      inv_vars=model["inv_vars"][off[j]:off[j + 1]]) for j in range(len(off) - 1)]
-        with tempfile.TemporaryDirectory() as d:
-            with kio.open_out(os.path.join(d, "am.mdl"), True) as f:
-                kio.write_am_diag_gmm(f, True, dim, pdfs, with_gconsts=False)
-            kio.write_ark(os.path.join(d, "feats.ark"), [("sample", feats)])
-            out = oracle.ref_driver("gmm-likes", os.path.join(d, "am.mdl"),
-                                    "ark:" + os.path.join(d, "feats.ark"),
-                                    "ark:" + os.path.join(d, "out.ark"))
-        secs = float(out.split()[1])
-        kind = "reference"
-    else:
-        t0 = time.time()
-        oracle.gmm_compute_likes(gconsts, model["means_invvars"], model["inv_vars"],
-                                 model["pdf_offsets"], feats)
-        secs = time.time() - t0
-        kind = "port"
-    return {"value": n / secs, "unit": "frames/s", "cores": 1, "kind": kind,
+
+        def make_args(d, feats_rspecifier):
+            mdl = os.path.join(d, "am.mdl")
+            if not os.path.exists(mdl):
+                with kio.open_out(mdl, True) as f:
+                    kio.write_am_diag_gmm(f, True, dim, pdfs, with_gconsts=False)
+            return ("gmm-likes", mdl, feats_rspecifier, "ark:/dev/null")
+
+        fps1, secs1, fps_all, secs_all = _ref_rates(
+            oracle, make_args, lambda w: [("sample%d" % w, synth.make_feats(model, n, seed=778 + w))], n, workers)
+        return {"value": fps1, "unit": "frames/s", "cores": 1, "kind": "reference",
+                "sample": "%d frames of the same synthetic workload, gmm-compute-likes loop, 1 thread, %.1f s"
+                          % (n, secs1),
+                "all_cores": {"value": fps_all, "unit": "frames/s", "cores": workers,
+                              "sample": "%d single-threaded processes side by side, %d frames each, %.1f s"
+                                        % (workers, n, secs_all)}}
+    feats = synth.make_feats(model, n, seed=778)
+    t0 = time.time()
+    oracle.gmm_compute_likes(gconsts, model["means_invvars"], model["inv_vars"],
+                             model["pdf_offsets"], feats)
+    secs = time.time() - t0
+    return {"value": n / secs, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d frames of the same synthetic workload, gmm-compute-likes loop, 1 thread, %.1f s" % (n, secs)}
+
+
+def cpu_baseline_nnet(seconds_target=8.0):
+    """The reference's nnet2 forward (NnetComputation + log, minus log-prior) on a bounded sample
+    of the p-norm workload; None when the reference library was not built."""
+    import oracle
+    from oracle import kaldi_io as kio
+    if not oracle.have_ref():
+        return None
+    comps, priors = synth.make_pnorm_nnet(seed=780)
+    lengths = synth.utterance_lengths(256, 200, 1500, seed=779)
+    want = seconds_target * 4000.0   # 1-thread reference: about 4-5 k frames/s
+    lengths = lengths[:max(1, int(np.searchsorted(np.cumsum(lengths), want)))]
+    n = int(lengths.sum())
+    workers = _cpu_workers()
+
+    def make_args(d, feats_rspecifier):
+        mdl = os.path.join(d, "nnet.mdl")
+        if not os.path.exists(mdl):
+            with kio.open_out(mdl, True) as f:
+                kio.write_am_nnet(f, True, comps, priors)
+        return ("nnet-loglikes", mdl, feats_rspecifier, "ark:/dev/null", "1", "1.0")
+
+    def items_for(w):
+        rng = np.random.default_rng(1780 + w)
+        return [("utt%d" % i, rng.normal(size=(int(t), 40)).astype(np.float32)) for i, t in enumerate(lengths)]
+
+    fps1, secs1, fps_all, secs_all = _ref_rates(oracle, make_args, items_for, n, workers)
+    return {"value": fps1, "unit": "frames/s", "cores": 1, "kind": "reference",
+            "sample": "%d frames in %d utterances, NnetComputation + log-likelihood conversion, 1 thread, %.1f s"
+                      % (n, len(lengths), secs1),
+            "all_cores": {"value": fps_all, "unit": "frames/s", "cores": workers,
+                          "sample": "%d single-threaded processes side by side, %d frames each, %.1f s"
+                                    % (workers, n, secs_all)}}
 
 
 def main():
@@ -214,6 +283,8 @@ def main():
                 from kaldi_amd import nnet_bench
                 line["config"]["nnet2_pnorm"] = nnet_bench.run(dev, stream, world,
                                                                utts_per_gpu=args.utts_per_gpu)
+                if world == 1 and not args.no_cpu_baseline:
+                    line["config"]["nnet2_pnorm"]["cpu_baseline"] = cpu_baseline_nnet()
             except ImportError:
                 pass
         print(json.dumps(line), flush=True)

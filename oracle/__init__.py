@@ -225,15 +225,37 @@ def have_ref():
     return os.path.exists(REF_DRIVER) and os.access(REF_DRIVER, os.X_OK)
 
 
-def ref_driver(*args, timeout=3600):
-    """Runs oracle/_ref/ref_driver (the real reference library). Returns stdout."""
+def _ref_env():
     env = dict(os.environ)
     env["MKL_THREADING_LAYER"] = "SEQUENTIAL"
     env["MKL_NUM_THREADS"] = "1"
     env["OMP_NUM_THREADS"] = "1"
     env["LD_LIBRARY_PATH"] = os.path.join(HERE, "_ref", "mkl")
-    p = subprocess.run([REF_DRIVER] + [str(a) for a in args], env=env, capture_output=True,
+    return env
+
+
+def ref_driver(*args, timeout=3600):
+    """Runs oracle/_ref/ref_driver (the real reference library). Returns stdout."""
+    p = subprocess.run([REF_DRIVER] + [str(a) for a in args], env=_ref_env(), capture_output=True,
                        text=True, timeout=timeout)
     if p.returncode != 0:
         raise RuntimeError("ref_driver %s failed (%d): %s" % (args[0], p.returncode, p.stderr[-2000:]))
     return p.stdout
+
+
+def ref_driver_many(arg_lists, timeout=3600):
+    """Runs one single-threaded ref_driver process per argument list, all at the same time (the
+    reference's JOB=1:$nj practice, steps/decode.sh:113).  Returns the list of stdouts."""
+    procs = [subprocess.Popen([REF_DRIVER] + [str(a) for a in args], env=_ref_env(),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for args in arg_lists]
+    outs = []
+    for args, p in zip(arg_lists, procs):
+        out, err = p.communicate(timeout=timeout)
+        if p.returncode != 0:
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            raise RuntimeError("ref_driver %s failed (%d): %s" % (args[0], p.returncode, err[-2000:]))
+        outs.append(out)
+    return outs
