@@ -223,3 +223,20 @@ def test_front_end_restatement_matches_the_reference():
         assert np.abs(oracle.transform_feats(a, mats["fmllr"]) - both).max() <= 2e-5
     with pytest.raises(ValueError):
         oracle.transform_feats(np.zeros((3, 5), np.float32), np.zeros((4, 7), np.float32))
+
+
+@needs_ref
+def test_bench_cpu_baseline_legs(monkeypatch):
+    """The benchmark's CPU-baseline legs: the reference library on a bounded sample, one process
+    and several side by side; both report frames/s of the sample they name."""
+    import importlib
+    import sys
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    monkeypatch.setenv("OMP_NUM_THREADS", "2")
+    bench = importlib.import_module("bench")
+    m = synth.make_gmm(39, 40, 400, seed=5)
+    r = bench.cpu_baseline_gmm(m, None, 39, seconds_target=0.05)
+    assert r["kind"] == "reference" and r["cores"] == 1 and r["value"] > 0
+    assert r["all_cores"]["cores"] == 2 and r["all_cores"]["value"] > 0
+    n = bench.cpu_baseline_nnet(seconds_target=0.1)
+    assert n["kind"] == "reference" and n["value"] > 0 and n["all_cores"]["value"] > 0
