@@ -52,8 +52,11 @@ F16X2_PRODUCTS = 3
 # rocprofv3 --pmc passes over the scoring kernel on the default workload (frames on rank 0 at
 # N = 1), KB per launch: profiles/r1_i_gmm_diff_pmc_summary.txt
 # tools/micro/peaks.hip on the same kind of box (profiles/r1_k_peaks.txt): dense
-# v_mfma_f32_32x32x16_f16 on every CU, four waves per SIMD
-MEASURED_F16_MFMA_TFLOPS = 2317.0
+# v_mfma_f32_32x32x16_f16 on every CU, four waves per SIMD, launches as long as this kernel's;
+# with the same small operands in every instruction, and with pseudo-random operands (the clock
+# the chip sustains under the matrix pipe depends on the switching activity of the data)
+MEASURED_F16_MFMA_TFLOPS = 2419.0
+MEASURED_F16_MFMA_TFLOPS_RANDOM = 1700.0
 PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 3246530.0, 8875470.0
 
 
@@ -276,8 +279,11 @@ def main():
                 "peak_basis": peak_basis,
                 "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
                 "frac_of_measured_peak": achieved / (peak * MEASURED_F16_MFMA_TFLOPS / BF16_MFMA_PEAK_TFLOPS),
-                "measured_peak_basis": "tools/micro/peaks.hip: 2317 TFLOP/s dense fp16 MFMA measured "
-                                       "(profiles/r1_k_peaks.txt), divided like peak",
+                "frac_of_measured_peak_random_operands":
+                    achieved / (peak * MEASURED_F16_MFMA_TFLOPS_RANDOM / BF16_MFMA_PEAK_TFLOPS),
+                "measured_peak_basis": "tools/micro/peaks.hip (profiles/r1_k_peaks.txt): dense fp16 MFMA sustains "
+                                       "2419 TFLOP/s on constant operands and 1700 TFLOP/s on random ones; "
+                                       "both divided like peak",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

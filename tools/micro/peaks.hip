@@ -20,19 +20,32 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     }                                                                            \
   } while (0)
 
-template <int THREADS>
+// RANDOM = false: the same small operands in every instruction (little switching activity);
+// RANDOM = true: four different pseudo-random operand pairs of mixed sign and magnitude per wave,
+// so that consecutive instructions toggle the multiplier inputs the way real data does (the
+// clock the chip sustains depends on it).
+template <int THREADS, bool RANDOM>
 __global__ void __launch_bounds__(THREADS) mfma_peak(float *out, int iters, float seed) {
-  f16x8 a, b;
-  for (int i = 0; i < 8; ++i) {
-    a[i] = (_Float16)(seed * (threadIdx.x + i));
-    b[i] = (_Float16)(seed * (i + 1));
-  }
+  f16x8 a[4], b[4];
+  unsigned r = 2654435761u * (blockIdx.x * THREADS + threadIdx.x + 1);
+  for (int q = 0; q < 4; ++q)
+    for (int i = 0; i < 8; ++i) {
+      if (RANDOM) {
+        r = r * 1664525u + 1013904223u;
+        a[q][i] = (_Float16)(((int)(r >> 8 & 0xffff) - 32768) * (1.0f / 16384.0f));
+        r = r * 1664525u + 1013904223u;
+        b[q][i] = (_Float16)(((int)(r >> 8 & 0xffff) - 32768) * (1.0f / 16384.0f));
+      } else {
+        a[q][i] = (_Float16)(seed * (threadIdx.x + i));
+        b[q][i] = (_Float16)(seed * (i + 1));
+      }
+    }
   f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
   for (int it = 0; it < iters; ++it) {
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
-    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
-    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[1], c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], b[2], c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[3], b[3], c3, 0, 0, 0);
   }
   float s = 0.0f;
   for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
@@ -72,16 +85,15 @@ static double time_ms(F launch, int reps) {
   return ms / reps;
 }
 
-template <int THREADS>
-static void run_mfma(float *d_out, int cus) {
-  const int iters = 20000;
-  const double ms = time_ms([&] { hipLaunchKernelGGL(mfma_peak<THREADS>, dim3(cus), dim3(THREADS), 0, 0, d_out, iters, 0.001f); }, 5);
+template <int THREADS, bool RANDOM>
+static void run_mfma(float *d_out, int cus, int iters) {
+  const double ms = time_ms([&] { hipLaunchKernelGGL((mfma_peak<THREADS, RANDOM>), dim3(cus), dim3(THREADS), 0, 0, d_out, iters, 0.001f); }, 5);
   const double n_mfma = (double)cus * (THREADS / 64) * iters * 4.0;
   const double tflops = n_mfma * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e12;
   // every SIMD issues (THREADS/256) waves' instructions back to back, 32 cycles each at full rate
   const double ghz = (double)(THREADS / 256) * iters * 4.0 * 32.0 / (ms * 1e-3) / 1e9;
-  printf("mfma_f32_32x32x16_f16  %d waves/SIMD on %d CUs: %8.1f TFLOP/s  (%.2f ms; %.2f GHz if 32 cycles per instruction)\n",
-         THREADS / 256, cus, tflops, ms, ghz);
+  printf("mfma_f32_32x32x16_f16  %s operands, %d waves/SIMD on %d CUs: %8.1f TFLOP/s  (%.2f ms per launch; %.2f GHz if 32 cycles per instruction)\n",
+         RANDOM ? "random  " : "constant", THREADS / 256, cus, tflops, ms, ghz);
 }
 
 int main() {
@@ -91,9 +103,14 @@ int main() {
   printf("%s, %d CUs, clockRate %.2f GHz\n", prop.gcnArchName, cus, prop.clockRate / 1e6);
   float *d_out;
   CHECK(hipMalloc(&d_out, (size_t)cus * 1024 * sizeof(float)));
-  run_mfma<256>(d_out, cus);
-  run_mfma<512>(d_out, cus);
-  run_mfma<1024>(d_out, cus);
+  // short launches (about 1-5 ms) and launches as long as the benchmark's kernel (20+ ms)
+  for (int iters : {20000, 150000}) {
+    run_mfma<256, false>(d_out, cus, iters);
+    run_mfma<512, false>(d_out, cus, iters);
+    run_mfma<1024, false>(d_out, cus, iters);
+    run_mfma<512, true>(d_out, cus, iters);
+    run_mfma<1024, true>(d_out, cus, iters);
+  }
 
   const size_t bytes = (size_t)8 << 30, n = bytes / 16;
   f32x4 *a, *b;
