@@ -16,6 +16,12 @@ D, P, G = synth.GMM_CONFIGS[cfg]
 t0 = time.time()
 m = synth.make_gmm(D, P, G, seed=777)
 feats = synth.make_feats(m, T, seed=778)
+# PERF_FEATS=zero|const: features with no / little switching activity (how much of the kernel's
+# time follows the clock the chip sustains on real data)
+if os.environ.get("PERF_FEATS") == "zero":
+    feats[:] = 0.0
+elif os.environ.get("PERF_FEATS") == "const":
+    feats[:] = feats[0]
 print("model+feats built in %.1fs  G=%d sizes: max %d" % (time.time() - t0, m["pdf_offsets"][-1],
       np.diff(m["pdf_offsets"]).max()), flush=True)
 _lib.check(_lib.lib().amlike_init(0))
