@@ -172,11 +172,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = "nccl"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        if ndev >= world:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            # Rehearsal on a box with fewer GPUs than ranks: ranks share devices, which RCCL does
+            # not allow, so the summary is reduced over gloo.  Not a scaling measurement.
+            backend = "gloo"
+            local_rank = local_rank % max(1, ndev)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -227,7 +237,7 @@ def main():
 
     # Summary statistics, all-reduced like the reference binaries' totals.
     (tot_like, tot_frames), elapsed = reduce_summary(
-        dist, [d_out.max(dim=1).values.double().sum().item(), float(T)], elapsed, device=dev)
+        dist, [d_out.max(dim=1).values.double().sum().item(), float(T)], elapsed, device=dev if backend == "nccl" else None)
 
     # Dominant kernel: mean of the event-bracketed durations collected over the timed region.
     if timed_launches == 0:  # more than 256 steps: fall back to a separate timing loop
@@ -266,7 +276,8 @@ def main():
                 "workload": "%s GMM gmm-compute-likes: D=%d, %d pdfs, %d Gaussians; %d utterances/GPU "
                             "(%d frames on rank 0) per step, dense [T x P] log-likelihoods kept in HBM"
                             % (args.config, D, P, G, args.utts_per_gpu, T),
-                "parallelism": "utterance-sharded x%d, no data-path collective" % world,
+                "parallelism": "utterance-sharded x%d, no data-path collective" % world +
+                               ("" if backend == "nccl" else " (rehearsal: ranks share GPUs, summary over gloo)"),
                 "kernel": am.kernel_info(),
                 "avg_best_pdf_loglike_per_frame": tot_like / tot_frames,
             },
