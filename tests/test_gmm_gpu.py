@@ -205,6 +205,24 @@ def test_log_sum_exp_prune(amlike_device, prune):
         assert np.abs(f - cutoff).min() < 1e-3, "entry (%d,%d) differs away from the cutoff" % (t, p)
 
 
+def test_log_sum_exp_prune_in_frame_chunks(amlike_device, monkeypatch):
+    """The pruned path bounds its [frames x Gaussians] scratch by working in frame chunks; the
+    chunking must not change a bit (1 MiB of scratch = chunks of 174 frames here), also when the
+    last chunk is shorter than 64 frames (which takes the small-batch score kernel)."""
+    m = synth.make_gmm(40, 60, 1500, seed=91)
+    feats = synth.make_feats(m, 560, seed=93)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    whole = am.LogLikelihoods(feats, log_sum_exp_prune=5.0)
+    monkeypatch.setenv("AMLIKE_GMM_PRUNE_SCRATCH_MB", "1")
+    chunked = am.LogLikelihoods(feats, log_sum_exp_prune=5.0)
+    assert np.abs(chunked - whole).max() <= 2e-5   # the two score kernels differ in summation order
+    np.testing.assert_array_equal(chunked[:522], whole[:522])
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    want, st = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"],
+                                        feats, prune=5.0)
+    assert st == 0 and (np.abs(chunked - want) >= TOL).mean() < 1e-3
+
+
 @pytest.mark.parametrize("mode", ["diff-f16x2", "diff-bf16x3"])
 def test_differenced_kernel_operand_types(amlike_device, mode, monkeypatch):
     monkeypatch.setenv("AMLIKE_GMM_MODE", mode)
