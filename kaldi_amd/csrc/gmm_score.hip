@@ -44,6 +44,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "amlike_common.h"
@@ -648,16 +649,52 @@ __global__ void __launch_bounds__(64 * W, OCC)
 //
 //  The model is packed relative to a reference Gaussian per pdf segment (PackModel,
 //    "differenced" image): slot 0 of a segment holds the reference itself (its score
-//    f_ref), every other slot holds (Gaussian - reference), so the matrix instructions
-//    deliver d_i = f_i - f_ref directly and
+//    f_ref, in natural-log units), every other slot holds (Gaussian - reference) in log2
+//    units, so the matrix instructions deliver d_i = f_i - f_ref directly and
 //        log sum_i exp f_i = f_ref + log(1 + sum_{i>0} exp d_i).
-//    The per-register work is v_exp_f32 + v_fma_f32 with a wave-uniform 0/1 factor that
-//    restarts the sum at segment boundaries; the pass over the 16*NT accumulator registers
-//    has no branch.  Every running sum is kept (sv), and a short loop over the wave's
-//    segments picks the sums at the segment ends by register index, joins the two
-//    half-waves and writes the results.  A sum that overflows (some Gaussian more than
-//    2^128 above the reference; PackModel makes the broadest Gaussian the reference, which
-//    keeps that rare) is listed in fix_list and recomputed exactly by gmm_fix_kernel.
+//    The per-register work (the "pass") is v_exp_f32 + v_fma_f32 with a wave-uniform 0/1
+//    factor that restarts the sum at segment boundaries; it has no branch.  Every running sum
+//    is kept (sv); the "tail" then picks the sums at the segment ends by register index, joins
+//    the two half-waves and writes the results.  A sum that overflows (some Gaussian more
+//    than 2^128 above the reference; PackModel makes the broadest Gaussian the reference,
+//    which keeps that rare) is listed in fix_list and recomputed exactly by gmm_fix_kernel.
+//
+//  The two waves that share a SIMD take turns on the matrix pipe: a wave in its tail issues no
+//    matrix instruction, so the tail of one should run beside the pass of the other, and it
+//    must be short.  The tail therefore works from per-wave tables prepared once (segment end
+//    registers packed in scalar registers, per-lane output offsets in LDS), handles two pairs
+//    of segments per step in straight-line code, and falls back to the general loop only for
+//    a block's ragged last frame tile and for chunks that hold a part of a split pdf.
+#ifdef AMLIKE_DIFF_STAMPS
+// Diagnostic build only: cycles (s_memtime) that each wave of one interior block spent in its
+// register passes, in its tails and in total: [wave][0..3] = pass, tail, total, tiles.
+__device__ unsigned long long g_diff_stamps[8 * 4];
+#define AMLIKE_STAMP() __builtin_readcyclecounter()
+#endif
+// AMLIKE_DIFF_PRIO 1: a wave in its pass gets issue priority over a wave in its tail; 3: the
+// other way round; 0: none.
+#ifndef AMLIKE_DIFF_PRIO
+#define AMLIKE_DIFF_PRIO 1
+#endif
+// AMLIKE_DIFF_PP 1: the waves of a SIMD alternate pass and tail under a barrier per phase
+// (see the kernel body); 0: every wave runs pass and tail back to back.
+#ifndef AMLIKE_DIFF_PP
+#define AMLIKE_DIFF_PP 0
+#endif
+// AMLIKE_DIFF_GCLDS 1: the gconsts are read from LDS into the accumulators before every tile
+// instead of living in 16 * NT registers.
+#ifndef AMLIKE_DIFF_GCLDS
+#define AMLIKE_DIFF_GCLDS AMLIKE_DIFF_PP
+#endif
+#ifndef AMLIKE_DIFF_FASTTAIL
+#define AMLIKE_DIFF_FASTTAIL 1
+#endif
+#ifndef AMLIKE_DIFF_PRE
+#define AMLIKE_DIFF_PRE 2
+#endif
+// Bytes of LDS per wave for the output-offset table of the differenced kernel's tail.
+constexpr int DiffTailTableBytes(int nt) { return (nt * 16 / 4) * 64 * 4; }
+
 template <int KS, int NT, int W, int OCC, int PREC, int ABL = 0>
 __global__ void __launch_bounds__(64 * W, OCC)
     gmm_score_diff_kernel(GmmPackView pk, ScoreArgs ar) {
@@ -666,8 +703,11 @@ __global__ void __launch_bounds__(64 * W, OCC)
   constexpr int kTileU4 = KS * NP * 64;
   constexpr int FTB = FramesTilesPerBarrier(W, KS, NP);
   constexpr int kSteps = NT * 16;
+  constexpr int kMaxPairs = kSteps / 4;  // a segment takes at least two registers
   static_assert(NT == 1 || NT == 2, "segment masks are 32 bits");
-  typedef float svec __attribute__((ext_vector_type(kSteps)));
+  // All accumulator registers of a lane as one vector: register r of the chunk is element r,
+  // whichever 32-Gaussian tile it belongs to.
+  typedef float accvec __attribute__((ext_vector_type(kSteps)));
   if (guard_skips(ar.ctl, ar.fix_cap, ar.guard)) return;
   int bx, by;
   {
@@ -682,9 +722,12 @@ __global__ void __launch_bounds__(64 * W, OCC)
   const int j = lane & 31, h = lane >> 5;
   const int wc = bx * W + w;
 
+  // LDS: [2 groups of FTB feature tiles][gconsts per wave][output-offset table per wave]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
   uint4 *s_b = reinterpret_cast<uint4 *>(smem_h);
   float *s_gc = reinterpret_cast<float *>(smem_h + 2 * FTB * kTileU4 * 16) + w * (NT * 32);
+  uint32_t *s_voff = reinterpret_cast<uint32_t *>(smem_h + 2 * FTB * kTileU4 * 16 + W * NT * 32 * 4) +
+                     w * (kMaxPairs * 64);
   for (int idx = lane; idx < NT * 32; idx += 64)
     s_gc[idx] = pk.gcpack[(size_t)wc * (NT * 32) + idx];
   const int colreg = lane < kSteps ? pk.segcol[(size_t)wc * kSteps + lane] : kColDiscard;
@@ -705,6 +748,30 @@ __global__ void __launch_bounds__(64 * W, OCC)
         if (seen == lane) endreg = r;
         ++seen;
       }
+  }
+  // Tables of the fast tail.  endw: the end registers of the segments, 5 bits each, six
+  // segments (three pairs) per word, in scalar registers.  s_voff[k][lane]: byte offset from
+  // the first output row of a frame tile to the element this lane writes for pair k (its own
+  // row, the column of segment 2k + h), or ~0 where it writes nothing (discarded padding,
+  // no segment).  A chunk that holds a part of a split pdf uses the general tail.
+  uint32_t endw[(kMaxPairs + 2) / 3];
+  bool fast_chunk;
+  {
+#pragma unroll
+    for (int q = 0; q < (kMaxPairs + 2) / 3; ++q) endw[q] = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxPairs; ++k) {
+      const int ea = __builtin_amdgcn_readlane(endreg, 2 * k);
+      const int eb = __builtin_amdgcn_readlane(endreg, 2 * k + 1);
+      endw[k / 3] |= (uint32_t)(ea | (eb << 5)) << (10 * (k % 3));
+      const int ca = __builtin_amdgcn_readlane(colreg, 2 * k);
+      const int cb = __builtin_amdgcn_readlane(colreg, 2 * k + 1);
+      const int c = h ? cb : ca;
+      s_voff[k * 64 + lane] = c >= 0 ? ((uint32_t)j * (uint32_t)ar.ldo + (uint32_t)c) * 4u : ~0u;
+    }
+    const bool part_here = lane < nseg && colreg < kColDiscard;
+    fast_chunk = AMLIKE_DIFF_FASTTAIL && __builtin_amdgcn_ballot_w64(part_here) == 0 &&
+                 (unsigned)ar.ldo < (1u << 24);
   }
 
   bf16x8 a[NT][KS][NP];
@@ -742,15 +809,6 @@ __global__ void __launch_bounds__(64 * W, OCC)
 
   constexpr int kMfma = KS * NPROD * NT;
   constexpr int kSkip = 2;
-#ifndef AMLIKE_DIFF_PRE
-#define AMLIKE_DIFF_PRE 2
-#endif
-  // AMLIKE_DIFF_PRIO 1: a wave in its register pass (the part that feeds the matrix pipe) gets
-  // issue priority over a wave in its segment loop (-3 % on the swbd shape); 2: priority
-  // around every matrix instruction (-2 %); 0: none.
-#ifndef AMLIKE_DIFF_PRIO
-#define AMLIKE_DIFF_PRIO 1
-#endif
   // Feature fragments are requested from LDS kPre k-steps before the matrix instructions
   // that read them (a wave that waits on LDS issues nothing, its matrix work included).
   constexpr int kPre = AMLIKE_DIFF_PRE < KS ? AMLIKE_DIFF_PRE : (KS > 1 ? KS - 1 : 1);
@@ -760,10 +818,46 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #pragma unroll
     for (int p = 0; p < NP; ++p) bf[s % NB][p] = __builtin_bit_cast(bf16x8, bt[(s * NP + p) * 64]);
   };
-  // The gconst image of this lane's accumulator registers, kept for the life of the wave:
-  // the first matrix instruction of every chain takes it as its C operand.
-  f32x16 gcv[NT];
-  auto mfma_n = [&](f32x16 (&acc)[NT], const uint4 *bt, int n) {
+  auto get_tile = [](const accvec &v, int nt) -> f32x16 {
+    if constexpr (NT == 1) {
+      return v;
+    } else {
+      return nt ? v.hi : v.lo;
+    }
+  };
+  auto set_tile = [](accvec &v, int nt, const f32x16 &t) {
+    if constexpr (NT == 1) {
+      v = t;
+    } else {
+      if (nt) v.hi = t;
+      else v.lo = t;
+    }
+  };
+  // The gconst image of this lane's accumulator registers: the first matrix instruction of every
+  // chain takes it as its C operand, either from registers kept for the life of the wave (gcv)
+  // or read from LDS into the accumulators before each tile (load_gc; 16 * NT registers fewer).
+  auto read_gc = [&](accvec &acc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float4 *g4 = reinterpret_cast<const float4 *>(&s_gc[nt * 32 + h * 16]);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        float4 v = g4[q4];
+        acc[16 * nt + 4 * q4 + 0] = v.x;
+        acc[16 * nt + 4 * q4 + 1] = v.y;
+        acc[16 * nt + 4 * q4 + 2] = v.z;
+        acc[16 * nt + 4 * q4 + 3] = v.w;
+      }
+    }
+  };
+#if AMLIKE_DIFF_GCLDS
+  auto load_gc = [&](accvec &acc) __attribute__((always_inline)) { read_gc(acc); };
+#else
+  accvec gcv;
+  read_gc(gcv);
+  auto load_gc = [&](accvec &) {};
+#endif
+  auto mfma_n = [&](accvec &acc, const uint4 *bt, int n) {
     const int s = n / (NPROD * NT), r = n % (NPROD * NT), which = r / NT, nt = r % NT;
     if (r == 0 && s + kPre < KS && !(ABL & 8)) load_b(bt, s + kPre);
     int pa, pb;  // (model part, feature part), small terms first
@@ -774,38 +868,25 @@ __global__ void __launch_bounds__(64 * W, OCC)
       pa = which == 0 ? 2 : (which == 1 || which == 3) ? 1 : 0;
       pb = (which == 0 || which == 3 || which == 5) ? 0 : (which == 1 || which == 4) ? 1 : 2;
     }
-    const f32x16 c = (s == 0 && which == 0) ? gcv[nt] : acc[nt];
-#if AMLIKE_DIFF_PRIO == 2
-    __builtin_amdgcn_s_setprio(2);
+#if AMLIKE_DIFF_GCLDS
+    f32x16 c = get_tile(acc, nt);  // the chain starts from the gconsts read into acc (load_gc)
+#else
+    f32x16 c = (s == 0 && which == 0) ? get_tile(gcv, nt) : get_tile(acc, nt);
 #endif
     if (PREC)
-      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[nt][s][pa]),
-                                                       __builtin_bit_cast(f16x8, bf[s % NB][pb]),
-                                                       c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[nt][s][pa]),
+                                                 __builtin_bit_cast(f16x8, bf[s % NB][pb]), c, 0, 0, 0);
     else
-      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][s][pa], bf[s % NB][pb], c, 0, 0, 0);
-#if AMLIKE_DIFF_PRIO == 2
-    __builtin_amdgcn_s_setprio(0);
-#endif
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[nt][s][pa], bf[s % NB][pb], c, 0, 0, 0);
+    set_tile(acc, nt, c);
   };
   auto load_b_head = [&](const uint4 *bt) {
 #pragma unroll
     for (int s = 0; s < kPre && s < KS; ++s) load_b(bt, s);
   };
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const float4 *g4 = reinterpret_cast<const float4 *>(&s_gc[nt * 32 + h * 16]);
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      float4 v = g4[q4];
-      gcv[nt][4 * q4 + 0] = v.x;
-      gcv[nt][4 * q4 + 1] = v.y;
-      gcv[nt][4 * q4 + 2] = v.z;
-      gcv[nt][4 * q4 + 3] = v.w;
-    }
-  }
 
-  f32x16 acc_cur[NT];
+  accvec acc_cur, acc_alt;
+  load_gc(acc_cur);
   load_b_head(s_b + lane);
 #pragma unroll
   for (int n = 0; n < kMfma; ++n) mfma_n(acc_cur, s_b + lane, n);
@@ -816,117 +897,289 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #pragma unroll
   for (int st = 0; st < kSteps; ++st) keepf[st] = scalar_bit_as_float(keepm, st);
 
-  for (int ft = 0; ft < ntile; ++ft) {
+  // Address (this lane's part) of staged feature tile `fn` in LDS.
+  auto tile_ptr = [&](int fn) { return s_b + (((fn / FTB) & 1) * FTB + fn % FTB) * kTileU4 + lane; };
+
+#ifdef AMLIKE_DIFF_STAMPS
+  unsigned long long stamp_pass = 0, stamp_tail = 0, stamp_tiles = 0;
+  const unsigned long long stamp_begin = AMLIKE_STAMP();
+  auto stamps_out = [&]() {
+    if (bx == ar.nbx / 2 && by == 1 && lane == 0) {
+      g_diff_stamps[w * 4 + 0] = stamp_pass;
+      g_diff_stamps[w * 4 + 1] = stamp_tail;
+      g_diff_stamps[w * 4 + 2] = AMLIKE_STAMP() - stamp_begin;
+      g_diff_stamps[w * 4 + 3] = stamp_tiles;
+    }
+  };
+#endif
+
+  // The register pass of frame tile ft: the running sums of its scores (acc_c) on the vector
+  // unit, with the matrix instructions of tile ft+1 (into acc_n) issued between them.
+  // preloaded: the feature fragments of the first kPre k-steps (and the gconsts, where they
+  // come from LDS) are already on their way.
+  accvec sv;
+  auto pass = [&](const int ft, accvec &acc_c, accvec &acc_n, auto preloaded_tag) __attribute__((always_inline)) {
+    constexpr bool preloaded = decltype(preloaded_tag)::value;
+    const uint4 *bt = tile_ptr(ft + 1);
+    if (!preloaded) {
+      load_gc(acc_n);
+      if (!(ABL & 8)) load_b_head(bt);
+    }
+    float s_ = 0.0f;
+#ifdef AMLIKE_DIFF_STAMPS
+    const unsigned long long st0 = AMLIKE_STAMP();
+#endif
+#if AMLIKE_DIFF_PRIO == 1
+    __builtin_amdgcn_s_setprio(2);
+#endif
+    // Leading steps without matrix work cover the LDS latency of the first fragments.
+    constexpr int skip = preloaded ? 0 : kSkip;
+    // exp of step st+1 is issued before the fma of step st consumes the exp of step st: no
+    // instruction waits on the result of the transcendental instruction just before it.
+    float e_cur = (ABL & 2) ? 0.0f : fast_exp2(acc_c[0]);
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) {
+#pragma unroll
+      for (int n = (max(st - skip, 0) * kMfma) / (kSteps - skip);
+           n < (max(st + 1 - skip, 0) * kMfma) / (kSteps - skip); ++n)
+        mfma_n(acc_n, bt, n);
+      // Nothing moves across: the matrix instructions stay spread over the vector work.
+      __builtin_amdgcn_sched_barrier(0);
+      if (ABL & 2) {
+        asm volatile("" ::"v"(acc_c[st]));
+      } else {
+        float e_next = 0.0f;
+        if (st + 1 < kSteps) e_next = fast_exp2(acc_c[st + 1]);
+        s_ = fmaf(s_, keepf[st], e_cur);  // keepf[st]: does the sum continue into this register?
+        // (pinned: the compiler would otherwise sink this arithmetic to where sv is read)
+        pin_order(e_next);
+        pin_order(s_);
+        e_cur = e_next;
+      }
+      sv[st] = s_;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#if AMLIKE_DIFF_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef AMLIKE_DIFF_STAMPS
+    stamp_pass += AMLIKE_STAMP() - st0;
+    ++stamp_tiles;
+#endif
+  };
+
+  auto report_overflow = [&](int row, int col) {
+    const int kk = atomicAdd(ar.ctl, 1);
+    if (kk < ar.fix_cap) ar.fix_list[kk] = make_int2(row, col);
+  };
+
+  // General tail: the segments of this wave's chunk for frame tile ft, two per iteration:
+  // lanes 0-31 finish segment 2k and lanes 32-63 segment 2k+1 of the same 32 frames.  One
+  // v_permlane32_swap of (value for a, value for b) leaves, in each half-wave, that half's
+  // segment as seen by both halves of the original layout.
+  auto tail_general = [&](const int ft, const accvec &acc_c) __attribute__((always_inline)) {
     const int t0 = t_begin + (ft << 5);
     const int row = t0 + j;
     float *orow = ar.out + (size_t)row * ar.ldo;
+    int start_a = 0;
+    for (int k = 0; k < npair; ++k) {
+      const int end_a = __builtin_amdgcn_readlane(endreg, 2 * k);
+      const int end_b = __builtin_amdgcn_readlane(endreg, 2 * k + 1);
+      const int col_a = __builtin_amdgcn_readlane(colreg, 2 * k);
+      const int col_b = __builtin_amdgcn_readlane(colreg, 2 * k + 1);
+      const int start_b = min(end_a + 1, kSteps - 1);
+      const auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(sv[end_a]),
+                                                       __float_as_uint(sv[end_b]), false, false);
+      const auto xx = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_c[start_a]),
+                                                       __float_as_uint(acc_c[start_b]), false, false);
+      // ss[0] / ss[1]: the sums of the even / odd slots; xx[0]: score of the reference
+      // Gaussian (slot 0, natural-log units), xx[1]: first difference (slot 1).
+      const float ref = __uint_as_float(xx[0]);
+      const float S = (1.0f + fast_exp2(__uint_as_float(xx[1]))) +
+                      (__uint_as_float(ss[0]) + __uint_as_float(ss[1]));
+      const int col = h ? col_b : col_a;
+      if (row < t_end) {
+        if (col >= 0) {
+          float v = fmaf(fast_log2(S), kLn2, ref);
+          if (!(ABL & 1)) orow[col] = v;
+          else pin_order(v);
+          if (!ABL && !(fabsf(v) <= kMaxAbsLogLike)) report_overflow(row, col);
+        } else if (col != kColDiscard && !(ABL & 1)) {  // a part of a split pdf
+          const size_t o = (size_t)(-col - 2) * ar.part_ld + row;
+          ar.part_m[o] = ref;
+          ar.part_s[o] = S;
+        }
+      }
+      start_a = min(end_b + 1, kSteps - 1);
+    }
+  };
 
+  // Fast tail (whole frame tiles of chunks without split-pdf parts): two pairs of segments per
+  // step, in straight-line code so that their dependent chains overlap; segment positions from
+  // endw, output offsets from s_voff, stores relative to the tile's first output row.
+  auto tail_fast = [&](const int ft, const accvec &acc_c) __attribute__((always_inline)) {
+    const int t0 = t_begin + (ft << 5);
+    char *tile_base = reinterpret_cast<char *>(ar.out) + (size_t)t0 * (size_t)ar.ldo * sizeof(float);
+    // Keep the packed words opaque per tile: the field extraction (scalar unit, cheap) is redone
+    // every tile instead of every field living in a scalar register of its own.
+#if __HIP_DEVICE_COMPILE__
+#pragma unroll
+    for (int q = 0; q < (kMaxPairs + 2) / 3; ++q) asm volatile("" : "+s"(endw[q]));
+#endif
+    auto end_of = [&](int seg) -> int { return (endw[seg / 6] >> (5 * (seg % 6))) & 31; };
+    auto finish = [&](int end_a, int end_b, int start_a, int start_b) -> float {
+      const auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(sv[end_a]),
+                                                       __float_as_uint(sv[end_b]), false, false);
+      const auto xx = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_c[start_a]),
+                                                       __float_as_uint(acc_c[start_b]), false, false);
+      const float S = (1.0f + fast_exp2(__uint_as_float(xx[1]))) +
+                      (__uint_as_float(ss[0]) + __uint_as_float(ss[1]));
+      return fmaf(fast_log2(S), kLn2, __uint_as_float(xx[0]));
+    };
+    auto emit = [&](float v, uint32_t voff) {
+      if (voff != ~0u) {
+        if (!(ABL & 1)) *reinterpret_cast<float *>(tile_base + voff) = v;
+        if (!ABL && !(fabsf(v) <= kMaxAbsLogLike))
+          report_overflow(t0 + j, (int)(voff / 4u - (uint32_t)j * (uint32_t)ar.ldo));
+      }
+    };
+#pragma unroll
+    for (int kk = 0; kk < (kMaxPairs + 1) / 2; ++kk) {
+      if (2 * kk >= npair) break;
+      const int ea0 = end_of(4 * kk), eb0 = end_of(4 * kk + 1);
+      const int sa0 = kk == 0 ? 0 : min(end_of(4 * kk - 1) + 1, kSteps - 1);
+      const int sb0 = min(ea0 + 1, kSteps - 1);
+      const uint32_t voff0 = s_voff[(2 * kk) * 64 + lane];
+      float v0 = finish(ea0, eb0, sa0, sb0);
+      if (2 * kk + 1 < kMaxPairs) {
+        const int ea1 = end_of(4 * kk + 2), eb1 = end_of(4 * kk + 3);
+        const int sa1 = min(eb0 + 1, kSteps - 1), sb1 = min(ea1 + 1, kSteps - 1);
+        const uint32_t voff1 = s_voff[(2 * kk + 1) * 64 + lane];
+        float v1 = finish(ea1, eb1, sa1, sb1);
+        // both values exist before either store's control flow starts
+        pin_order(v0);
+        pin_order(v1);
+        emit(v0, voff0);
+        emit(v1, voff1);
+      } else {
+        pin_order(v0);
+        emit(v0, voff0);
+      }
+    }
+  };
+
+  auto tail = [&](const int ft, const accvec &acc_c) __attribute__((always_inline)) {
+#ifdef AMLIKE_DIFF_STAMPS
+    const unsigned long long st0 = AMLIKE_STAMP();
+#endif
+#if AMLIKE_DIFF_PRIO == 3
+    __builtin_amdgcn_s_setprio(2);
+#endif
+    if (ABL & 4) {
+      accvec keep = sv;
+      pin_order(keep);
+    } else if (fast_chunk && t_begin + (ft << 5) + 32 <= t_end) {
+      tail_fast(ft, acc_c);
+    } else {
+      tail_general(ft, acc_c);
+    }
+#if AMLIKE_DIFF_PRIO == 3
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef AMLIKE_DIFF_STAMPS
+    stamp_tail += AMLIKE_STAMP() - st0;
+#endif
+  };
+
+  if (AMLIKE_DIFF_PP && W == 8 && !(ABL & 16)) {
+    // Ping-pong.  The two waves that share a SIMD (w and w + 4) alternate: while one is in its
+    // register pass and owns the matrix pipe, the other finishes the segments of its previous
+    // tile; a barrier separates the phases, and waves 4-7 run one phase behind waves 0-3.
+    // Phase p: waves 0-3 pass(p/2) for even p, tail(p/2) for odd p; waves 4-7 the same for p-1.
+    // Staged feature group G (tiles G*FTB ..) is first touched in phase 2*G*FTB - 3 (the fragment
+    // preload of waves 0-3 for pass(G*FTB - 1)) and last in phase 2*G*FTB + 2*FTB - 3.
+    // Tiles are taken in pairs (the two accumulator sets exchange roles); a tile past the end of
+    // the block's frames computes on stale LDS contents and stores nothing.
+    constexpr int PB = 2 * FTB;  // phases per staged group
+    auto phase_sync = [&](const int p) __attribute__((always_inline)) {
+      if ((p + 3) % PB == 0) wait_vector_memory();  // this wave's share of the next group has landed
+      __syncthreads();
+      if ((p + 2) % PB == 0) {
+        const int G = (p + 2) / PB;
+        if (G + 1 < ngroup) stage(G + 1);
+      }
+    };
+    // What the next pass needs first, requested before the barrier in front of it: the feature
+    // fragments of the first k-steps of tile fn and the gconsts in the accumulators it writes.
+    auto preload = [&](const int fn, accvec &acc) __attribute__((always_inline)) {
+      load_gc(acc);
+      if (!(ABL & 8)) load_b_head(tile_ptr(fn));
+    };
+    auto tail_if = [&](const int ft, const accvec &acc) __attribute__((always_inline)) {
+      if (ft < ntile) tail(ft, acc);
+    };
+    const int npairs = (ntile + 1) >> 1;
+    if (w < W / 2) {
+      preload(1, acc_alt);
+      for (int m = 0; m < npairs; ++m) {
+        if (m > 0) phase_sync(4 * m);
+        pass(2 * m, acc_cur, acc_alt, std::true_type());
+        phase_sync(4 * m + 1);
+        tail_if(2 * m, acc_cur);
+        preload(2 * m + 2, acc_cur);
+        phase_sync(4 * m + 2);
+        pass(2 * m + 1, acc_alt, acc_cur, std::true_type());
+        phase_sync(4 * m + 3);
+        tail_if(2 * m + 1, acc_alt);
+        preload(2 * m + 3, acc_alt);
+      }
+    } else {
+      for (int m = 0; m < npairs; ++m) {
+        if (m > 0) {
+          phase_sync(4 * m);
+          tail_if(2 * m - 1, acc_alt);
+        }
+        preload(2 * m + 1, acc_alt);
+        phase_sync(4 * m + 1);
+        pass(2 * m, acc_cur, acc_alt, std::true_type());
+        phase_sync(4 * m + 2);
+        tail_if(2 * m, acc_cur);
+        preload(2 * m + 2, acc_cur);
+        phase_sync(4 * m + 3);
+        pass(2 * m + 1, acc_alt, acc_cur, std::true_type());
+      }
+      tail_if(2 * npairs - 1, acc_alt);
+    }
+#ifdef AMLIKE_DIFF_STAMPS
+    stamps_out();
+#endif
+    return;
+  }
+  // Lockstep: every wave runs pass and tail of a tile back to back; one barrier per staged
+  // group.  Two copies of the tile body with the roles of the two accumulator sets exchanged:
+  // no register copies between tiles.
+  auto tile_body = [&](const int ft, accvec &a_cur, accvec &a_next) __attribute__((always_inline)) {
     const int fn = ft + 1;
     if (fn % FTB == 0 && !(ABL & 16)) {
       __syncthreads();
       const int g = fn / FTB;
       if (g + 1 < ngroup) stage(g + 1);
     }
-    const uint4 *bt = s_b + (((fn / FTB) & 1) * FTB + fn % FTB) * kTileU4 + lane;
-    f32x16 acc_next[NT];
-    if (!(ABL & 8)) load_b_head(bt);
-
-    // Pass over the registers: matrix instructions of frame tile ft+1 interleaved with
-    // the running sums of tile ft.
-    svec sv;
-    float s_ = 0.0f;
-#if AMLIKE_DIFF_PRIO == 1
-    __builtin_amdgcn_s_setprio(2);
-#endif
-#pragma unroll
-    for (int st = 0; st < kSteps; ++st) {
-      const int nt = st >> 4, i = st & 15;
-#pragma unroll
-      for (int n = (max(st - kSkip, 0) * kMfma) / (kSteps - kSkip);
-           n < (max(st + 1 - kSkip, 0) * kMfma) / (kSteps - kSkip); ++n)
-        mfma_n(acc_next, bt, n);
-      // Pin the order: without this the compiler gathers all matrix instructions of the
-      // tile in front of the vector work and the two no longer overlap inside the wave.
-#pragma unroll
-      for (int q = 0; q < NT; ++q) pin_order(acc_next[q]);
-      if (ABL & 2) {
-        asm volatile("" ::"v"(acc_cur[nt][i]));
-      } else {
-        // keepf[st]: does the sum continue into this register?
-        s_ = fmaf(s_, keepf[st], fast_exp2(acc_cur[nt][i]));
-        pin_order(s_);
-      }
-      sv[st] = s_;
-    }
-
-#if AMLIKE_DIFF_PRIO == 1
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    pass(ft, a_cur, a_next, std::false_type());
     // The next iteration opens with the barrier that publishes a staged group: see this wave's
     // staging loads (issued FTB tiles ago) complete here, before this tile's stores join the
     // queue, rather than at the barrier itself, where the wait would also cover those stores.
     if ((ft + 2) % FTB == 0 && !(ABL & 16)) wait_vector_memory();
-    // Loop over the segments of this wave's chunk, two per iteration: lanes 0-31 finish
-    // segment 2k and lanes 32-63 segment 2k+1 of the same 32 frames.  One
-    // v_permlane32_swap of (value for a, value for b) leaves, in each half-wave, that
-    // half's segment as seen by both halves of the original layout.
-    if (!(ABL & 4)) {
-      int start_a = 0;
-      for (int k = 0; k < npair; ++k) {
-        const int end_a = __builtin_amdgcn_readlane(endreg, 2 * k);
-        const int end_b = __builtin_amdgcn_readlane(endreg, 2 * k + 1);
-        const int col_a = __builtin_amdgcn_readlane(colreg, 2 * k);
-        const int col_b = __builtin_amdgcn_readlane(colreg, 2 * k + 1);
-        const int start_b = min(end_a + 1, kSteps - 1);
-        auto acc_at = [&](int r) {
-          float x = acc_cur[0][r & 15];
-          if (NT == 2) {
-            const float x1 = acc_cur[NT - 1][r & 15];
-            x = r >= 16 ? x1 : x;
-          }
-          return x;
-        };
-        const auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(sv[end_a]),
-                                                         __float_as_uint(sv[end_b]), false, false);
-        const auto xx = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_at(start_a)),
-                                                         __float_as_uint(acc_at(start_b)), false, false);
-        // ss[0] / ss[1]: the sums of the even / odd slots; xx[0]: score of the reference
-        // Gaussian (slot 0), xx[1]: first difference (slot 1).
-        const float ref = __uint_as_float(xx[0]);
-        const float S = (1.0f + fast_exp2(__uint_as_float(xx[1]))) +
-                        (__uint_as_float(ss[0]) + __uint_as_float(ss[1]));
-        const int col = h ? col_b : col_a;
-        if (row < t_end) {
-          if (col >= 0) {
-            float v = (ref + fast_log2(S)) * kLn2;
-            if (ABL & 32) {
-              // timing experiment: the same number of store instructions, but 64 consecutive floats
-              ar.out[(size_t)min(t0 + (col & 31), ar.T - 2) * ar.ldo + (col & ~31) + lane] = v;
-            } else if (!(ABL & 1)) {
-              // (a non-temporal store here triples the kernel time: these 4-byte stores rely on
-              // L2 to merge the columns of neighbouring pdfs into full lines)
-              orow[col] = v;
-            } else {
-              pin_order(v);
-            }
-            if (!ABL && !(fabsf(v) <= kMaxAbsLogLike)) {
-              const int kk = atomicAdd(ar.ctl, 1);
-              if (kk < ar.fix_cap) ar.fix_list[kk] = make_int2(row, col);
-            }
-          } else if (col != kColDiscard && !(ABL & 1)) {  // parts are merged in natural-log units
-            const size_t o = (size_t)(-col - 2) * ar.part_ld + row;
-            ar.part_m[o] = ref * kLn2;
-            ar.part_s[o] = S;
-          }
-        }
-        start_a = min(end_b + 1, kSteps - 1);
-      }
-    } else {
-      pin_order(sv);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc_cur[nt] = acc_next[nt];
+    tail(ft, a_cur);
+  };
+  for (int ft = 0; ft < ntile; ft += 2) {
+    tile_body(ft, acc_cur, acc_alt);
+    if (ft + 1 >= ntile) break;
+    tile_body(ft + 1, acc_alt, acc_cur);
   }
+#ifdef AMLIKE_DIFF_STAMPS
+  stamps_out();
+#endif
 }
 
 // Recomputes the listed (frame, pdf) pairs in plain fp32 with the reference's own
@@ -1293,7 +1546,6 @@ static const Variant kVariants[] = {
     AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 2), AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 4),
     AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 6), AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 14),
     AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 30), AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 8),
-    AMLIKE_VARIANT_DABL(5, 2, 8, 2, 1, 32),
 #endif
     AMLIKE_VARIANT(40, 3, 8), AMLIKE_VARIANT(39, 3, 8),
     AMLIKE_VARIANT(40, 6, 4), AMLIKE_VARIANT(39, 6, 4),
@@ -1491,20 +1743,24 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
       if (!std::isfinite(gconsts[p.g_begin + q])) o[--hi] = p.g_begin + q;
     std::stable_sort(o, o + lo, [&](int x, int y) { return logdet[x] < logdet[y]; });
   }
-  // Operand value of Gaussian gi, kind (0: miv, 1: -0.5 iv), dimension d, in log2 units;
-  // `ref` >= 0: differenced against Gaussian ref.  Disabled Gaussians have zero operands.
+  // Operand value of Gaussian gi, kind (0: miv, 1: -0.5 iv), dimension d; `ref` >= 0:
+  // differenced against Gaussian ref, in log2 units.  ref < 0: the Gaussian as it is, in log2
+  // units, except in the differenced image, where it is a segment's reference and stays in
+  // natural-log units (the kernel adds it to ln(sum) unscaled).  Disabled Gaussians have zero
+  // operands.
+  const double raw_unit = vmode == 3 ? 1.0 : (double)kLog2e;
   auto opval = [&](int gi, int ref, int kind, int d) -> float {
     if (!std::isfinite(gconsts[gi])) return 0.0f;
     auto raw = [&](int x) -> double {
       return kind ? -0.5 * (double)iv[(size_t)x * D + d] : (double)miv[(size_t)x * D + d];
     };
-    const double v = ref >= 0 ? raw(gi) - raw(ref) : raw(gi);
-    return (float)(v * (double)kLog2e);
+    return (float)(ref >= 0 ? (raw(gi) - raw(ref)) * (double)kLog2e : raw(gi) * raw_unit);
   };
   auto gcval = [&](int gi, int ref) -> float {
     if (!std::isfinite(gconsts[gi])) return kPadGconst;
-    const double v = ref >= 0 ? (double)gconsts[gi] - (double)gconsts[ref] : (double)gconsts[gi];
-    return std::max((float)(v * (double)kLog2e), kPadGconst);
+    const double v = ref >= 0 ? ((double)gconsts[gi] - (double)gconsts[ref]) * (double)kLog2e
+                              : (double)gconsts[gi] * raw_unit;
+    return std::max((float)v, kPadGconst);
   };
   const bool want_diff = vmode == 3;
   // Slots a piece of `count` Gaussians occupies: an even number; the differenced kernels
@@ -1801,7 +2057,8 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
                          g->dim, static_cast<uint4 *>(ws->ptr), num_ftiles, g->d_bscale, g->d_ctl,
                          a.fix_cap, guard == 2 ? 2 : 0);
       AMLIKE_HIP(hipGetLastError());
-      smem = 2 * FramesTilesPerBarrier(v.W, KS, parts) * tile_bytes + (size_t)v.W * v.NT * 32 * 4;
+      smem = 2 * FramesTilesPerBarrier(v.W, KS, parts) * tile_bytes + (size_t)v.W * v.NT * 32 * 4 +
+             (size_t)v.W * DiffTailTableBytes(v.NT);
       if (smem > 64 * 1024)
         AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -2449,6 +2706,17 @@ int amlike_gmm_time_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, 
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *ms_per_launch = ms / iters;
+#ifdef AMLIKE_DIFF_STAMPS
+  {
+    unsigned long long hs[8 * 4];
+    if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_diff_stamps), sizeof(hs)) == hipSuccess)
+      for (int wv = 0; wv < 8; ++wv) {
+        const double n = (double)std::max(1ull, hs[wv * 4 + 3]);
+        fprintf(stderr, "stamps wave %d: tiles %llu  pass %.0f  tail %.0f  total/tile %.0f (cycle-counter ticks)\n",
+                wv, hs[wv * 4 + 3], hs[wv * 4] / n, hs[wv * 4 + 1] / n, hs[wv * 4 + 2] / n);
+      }
+  }
+#endif
   return AMLIKE_OK;
 }
 
