@@ -4,6 +4,7 @@
 //   amlike-copy feats <rspecifier> <wspecifier>
 //   amlike-copy nnet-info <mdl-in>                           TransitionModel + AmNnet, or AmNnet alone
 //   amlike-copy tid2pdf <mdl-in>                             prints "tid pdf" lines
+//   amlike-copy topo-info <topo-in>                          a <Topology> object alone: per phone, its states
 #include <iostream>
 #include <string>
 
@@ -15,7 +16,7 @@
 int main(int argc, char *argv[]) {
   using namespace kaldi_amd;
   try {
-    ParseOptions po("amlike-copy <gmm|feats|nnet-info|tid2pdf> ...");
+    ParseOptions po("amlike-copy <gmm|feats|nnet-info|tid2pdf|topo-info> ...");
     bool binary_out = true;
     po.Register("binary", &binary_out, "Write output in binary mode");
     po.Read(argc, argv);
@@ -71,6 +72,21 @@ int main(int argc, char *argv[]) {
       tm.Read(ki.Stream(), binary);
       for (int32 tid = 1; tid <= tm.NumTransitionIds(); ++tid)
         std::cout << tid << " " << tm.TransitionIdToPdf(tid) << "\n";
+      return 0;
+    } else if (cmd == "topo-info" && po.NumArgs() == 2) {
+      // one line per (phone, state): phone num-pdf-classes state pdf-class then dst:prob per transition
+      bool binary;
+      Input ki(po.GetArg(2), &binary);
+      TransitionModel tm;
+      tm.ReadTopology(ki.Stream(), binary);
+      for (int32 phone : tm.GetPhones()) {
+        const auto &entry = tm.TopologyForPhone(phone);
+        for (size_t st = 0; st < entry.size(); ++st) {
+          std::cout << phone << " " << tm.NumPdfClasses(phone) << " " << st << " " << entry[st].pdf_class;
+          for (const auto &tr : entry[st].transitions) std::cout << " " << tr.first << ":" << tr.second;
+          std::cout << "\n";
+        }
+      }
       return 0;
     }
     po.PrintUsage();

@@ -686,6 +686,9 @@ __device__ unsigned long long g_diff_stamps[8 * 4];
 #ifndef AMLIKE_DIFF_GCLDS
 #define AMLIKE_DIFF_GCLDS AMLIKE_DIFF_PP
 #endif
+#ifndef AMLIKE_DIFF_STAGGER
+#define AMLIKE_DIFF_STAGGER 1
+#endif
 #ifndef AMLIKE_DIFF_FASTTAIL
 #define AMLIKE_DIFF_FASTTAIL 1
 #endif
@@ -1155,21 +1158,32 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #endif
     return;
   }
-  // Lockstep: every wave runs pass and tail of a tile back to back; one barrier per staged
-  // group.  Two copies of the tile body with the roles of the two accumulator sets exchanged:
-  // no register copies between tiles.
+  // Every wave runs pass and tail of a tile back to back; one barrier per staged group.  The two
+  // waves of a SIMD (w and w + W/2) settle into taking turns on the matrix pipe -- one in its
+  // pass while the other is in its tail -- so the barrier of a group sits half a tile apart in
+  // their programs: waves of the first half meet it in front of the pass that first reads the
+  // group, waves of the second half (AMLIKE_DIFF_STAGGER) behind the pass before that one, in
+  // front of its tail.  By then every wave has finished the pass that last read the group which
+  // the new staging loads overwrite.  Two copies of the tile body with the roles of the two
+  // accumulator sets exchanged: no register copies between tiles.
+  // (Both halves must pass the same number of barriers: the second half skips the one whose
+  // tile the first half never starts, and with one tile per group there is no room to shift.)
+  const bool late_half = AMLIKE_DIFF_STAGGER && W == 8 && FTB >= 2 && w >= W / 2;
+  auto group_barrier = [&](const int g) __attribute__((always_inline)) {
+    __syncthreads();
+    if (g + 1 < ngroup) stage(g + 1);
+  };
   auto tile_body = [&](const int ft, accvec &a_cur, accvec &a_next) __attribute__((always_inline)) {
     const int fn = ft + 1;
-    if (fn % FTB == 0 && !(ABL & 16)) {
-      __syncthreads();
-      const int g = fn / FTB;
-      if (g + 1 < ngroup) stage(g + 1);
-    }
+    if (fn % FTB == 0 && !(ABL & 16) && !late_half) group_barrier(fn / FTB);
     pass(ft, a_cur, a_next, std::false_type());
-    // The next iteration opens with the barrier that publishes a staged group: see this wave's
-    // staging loads (issued FTB tiles ago) complete here, before this tile's stores join the
-    // queue, rather than at the barrier itself, where the wait would also cover those stores.
-    if ((ft + 2) % FTB == 0 && !(ABL & 16)) wait_vector_memory();
+    // The barrier publishes a staged group: see this wave's staging loads (issued FTB tiles ago)
+    // complete here, before this tile's stores join the queue, rather than at the barrier
+    // itself, where the wait would also cover those stores.
+    if ((ft + 2) % FTB == 0 && !(ABL & 16)) {
+      wait_vector_memory();
+      if (late_half && ft + 1 < ntile) group_barrier((ft + 2) / FTB);
+    }
     tail(ft, a_cur);
   };
   for (int ft = 0; ft < ntile; ft += 2) {

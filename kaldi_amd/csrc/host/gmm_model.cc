@@ -103,6 +103,19 @@ void TransitionModel::ReadTopology(std::istream &is, bool binary) {
       KaldiErr("HmmTopology::Check(), phone has no valid index.");
 }
 
+const std::vector<TransitionModel::HmmState> &TransitionModel::TopologyForPhone(int32 phone) const {
+  // hmm/hmm-topology.cc:273-281
+  if (phone < 0 || static_cast<size_t>(phone) >= phone2idx_.size() || phone2idx_[phone] == -1)
+    KALDI_AMD_ERR("TopologyForPhone(), phone " << phone << " not covered.");
+  return entries_[phone2idx_[phone]];
+}
+
+int32 TransitionModel::NumPdfClasses(int32 phone) const {  // hmm/hmm-topology.cc:283-292
+  int32 max_pdf_class = 0;
+  for (const HmmState &st : TopologyForPhone(phone)) max_pdf_class = std::max(max_pdf_class, st.pdf_class);
+  return max_pdf_class + 1;
+}
+
 void TransitionModel::ComputeDerived() {  // hmm/transition-model.cc:72-97
   state2id_.assign(triples_.size() + 2, 0);
   int32 cur = 1;

@@ -32,15 +32,20 @@ class TransitionModel {
   int32 TransitionIdToPdf(int32 trans_id) const;  // trans_id is 1-based
   const std::vector<int32> &TidToPdfTable() const { return tid2pdf_; }  // index 0 unused
 
+  // The HmmTopology part (hmm/hmm-topology.h:105-160): one entry of states per group of phones.
+  struct HmmState {
+    int32 pdf_class;  // -1 (kNoPdf) for a non-emitting state
+    std::vector<std::pair<int32, float>> transitions;  // (destination state, probability)
+  };
+  void ReadTopology(std::istream &is, bool binary);  // HmmTopology::Read, a <Topology> object alone
+  const std::vector<int32> &GetPhones() const { return phones_; }  // sorted
+  const std::vector<HmmState> &TopologyForPhone(int32 phone) const;
+  int32 NumPdfClasses(int32 phone) const;  // 1 + the largest pdf class of the phone's entry
+
  private:
   struct Triple {
     int32 phone, hmm_state, pdf;
   };
-  struct HmmState {
-    int32 pdf_class;
-    std::vector<std::pair<int32, float>> transitions;
-  };
-  void ReadTopology(std::istream &is, bool binary);
   void ComputeDerived();
   std::vector<int32> phones_, phone2idx_;
   std::vector<std::vector<HmmState>> entries_;

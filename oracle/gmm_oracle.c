@@ -5,7 +5,7 @@
  * smoke() and bench.py's cpu_baseline leg compare the HIP path against; the
  * product never links, loads or calls it.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks every function
+ * Parity status: PINNED.  tests/test_oracle_cpu.py checks every function
  * here against the real reference library (oracle/_ref/ref_driver, built from
  * /root/reference by oracle/build_ref.sh) and against the golden fixtures in
  * tests/golden/ that the same driver produced.

@@ -5,7 +5,7 @@
  * GPU is selected, which is how nnet-am-compute runs in the reference).  The
  * product never links, loads or calls it.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks it against the real
+ * Parity status: PINNED.  tests/test_oracle_cpu.py checks it against the real
  * reference library (oracle/_ref/ref_driver nnet-compute / nnet-loglikes) and
  * against golden fixtures that driver produced.
  *

@@ -76,6 +76,26 @@ def test_gmm_compute_likes_binary(gmm_files, fpb):
         assert (l.argmax(1) == want.argmax(1)).mean() >= 0.9999
 
 
+def test_gmm_compute_likes_yesno_shape(tmp_path):
+    """The yesno monophone configuration of the benchmark definition (D=39, 11 pdfs, 400 Gaussians,
+    30 utterances of 500 frames) file to file, against the oracle."""
+    D, P, G = synth.GMM_CONFIGS["yesno_mono"]
+    model = synth.make_gmm(D, P, G, seed=777)
+    write_gmm_mdl(str(tmp_path / "final.mdl"), model)
+    items = [("yesno%02d" % i, synth.make_feats(model, 500, seed=800 + i)) for i in range(30)]
+    kio.write_ark(str(tmp_path / "feats.ark"), items)
+    out = str(tmp_path / "likes.ark")
+    p = run("gmm-compute-likes", str(tmp_path / "final.mdl"), "ark:" + str(tmp_path / "feats.ark"), "ark:" + out)
+    assert b"computed likelihoods for 30 utterances" in p.stderr
+    got = kio.read_ark(out)
+    assert [k for k, _ in got] == [k for k, _ in items]
+    want = oracle_gmm(model, np.concatenate([f for _, f in items]))
+    have = np.concatenate([l for _, l in got])
+    assert have.shape == want.shape == (15000, P)
+    assert np.abs(have - want).max() <= TOL
+    assert (have.argmax(1) == want.argmax(1)).mean() >= 0.9999
+
+
 def test_gmm_compute_likes_text_model_and_text_output(gmm_files, tmp_path):
     d, model, items, _ = gmm_files
     small = synth.make_gmm(13, 9, 40, seed=22)

@@ -10,6 +10,7 @@ import pytest
 import oracle
 from oracle import kaldi_io as kio
 from kaldi_amd import synth
+from golden_util import gpath
 
 BIN = os.path.join(os.path.dirname(__file__), "..", "kaldi_amd", "csrc", "bin")
 COPY = os.path.join(BIN, "amlike-copy")
@@ -84,10 +85,58 @@ def test_am_gmm_write_matches_reference_bytes(tmp_path, binary):
     assert open(back, "rb").read() == open(str(tmp_path / "ours_bin.mdl"), "rb").read()
 
 
+# The text <Topology> files below are the reference's own (egs/yesno/s5/conf/topo_orig.proto,
+# egs/timit/s3/conf/topo.proto), with NONSILENCEPHONES / SILENCEPHONES replaced by phone ids the
+# way the recipes do it (egs/timit/s3/local/timit_format_data.sh:130: silence = 1, the others 2..).
+# What HmmTopology::Read must make of them is written out by hand here from the file text and
+# hmm/hmm-topology.cc:41-114 (entries, pdf classes, transitions) -- not taken from this
+# repository's Python writer.
+SIL_ENTRY = [(0, [(0, .25), (1, .25), (2, .25), (3, .25)]), (1, [(1, .25), (2, .25), (3, .25), (4, .25)]),
+             (2, [(1, .25), (2, .25), (3, .25), (4, .25)]), (3, [(1, .25), (2, .25), (3, .25), (4, .25)]),
+             (4, [(4, .25), (5, .75)]), (-1, [])]
+NONSIL_ENTRY = [(0, [(0, .75), (1, .25)]), (1, [(1, .75), (2, .25)]), (2, [(2, .75), (3, .25)]), (-1, [])]
+
+
+@pytest.mark.parametrize("name,nonsil", [("topo_yesno.txt", [2, 3]), ("topo_timit.txt", list(range(2, 50)))])
+def test_topology_files_of_the_reference_recipes(name, nonsil):
+    out, _ = run("topo-info", gpath(name))
+    got = {}
+    for line in out.strip().splitlines():
+        f = line.split()
+        phone, npdfclass, state, pdf_class = (int(x) for x in f[:4])
+        trans = [(int(t.split(":")[0]), float(t.split(":")[1])) for t in f[4:]]
+        got.setdefault(phone, (npdfclass, []))[1].append((state, pdf_class, trans))
+    assert sorted(got) == [1] + nonsil
+    for phone, (npdfclass, states) in got.items():
+        entry = SIL_ENTRY if phone == 1 else NONSIL_ENTRY
+        assert npdfclass == (5 if phone == 1 else 3)
+        assert [s for s, _, _ in states] == list(range(len(entry)))
+        assert [(pc, tr) for _, pc, tr in states] == entry
+
+
+def test_tid2pdf_on_the_reference_topology(tmp_path):
+    """Transition-ids by hand (hmm/transition-model.cc:72-97): transition-states are the triples in
+    order; each owns as many consecutive transition-ids, from 1, as its HMM state has transitions
+    in the topology -- 4 for silence states 0-3, 2 for silence state 4 and for every other state."""
+    topo = open(gpath("topo_yesno.txt")).read()
+    triples = [(1, 0, 0), (1, 1, 1), (1, 2, 2), (1, 3, 3), (1, 4, 4),
+               (2, 0, 5), (2, 1, 6), (2, 2, 7), (3, 0, 8), (3, 1, 9), (3, 2, 7)]
+    want = [0] * 4 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 2 + [5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 7, 7]
+    text = "<TransitionModel> \n" + topo + "<Triples> %d \n" % len(triples) + \
+        "".join("%d %d %d \n" % t for t in triples) + "</Triples> \n<LogProbs> \n [ " + \
+        " ".join(["0"] * (len(want) + 1)) + " ]\n</LogProbs> \n</TransitionModel> \n"
+    src = str(tmp_path / "trans.txt")
+    open(src, "w").write(text)
+    out, _ = run("tid2pdf", src)
+    rows = [[int(x) for x in line.split()] for line in out.strip().splitlines()]
+    assert [r[0] for r in rows] == list(range(1, len(want) + 1))
+    assert [r[1] for r in rows] == want
+
+
 @pytest.mark.parametrize("binary", [True, False])
 def test_transition_model_tid2pdf(tmp_path, binary):
-    # The reference's TransitionModel cannot be built here (it needs OpenFst headers),
-    # so this parser is checked against the Python restatement only: parity unpinned.
+    # Round trip with this repository's own Python writer (binary and text forms); the parser
+    # itself is pinned by the two tests above.
     model = synth.make_gmm(5, 10, 20, seed=7)
     src = str(tmp_path / "in.mdl")
     tid2pdf = write_gmm_mdl(src, model, binary)

@@ -240,3 +240,23 @@ def test_bench_cpu_baseline_legs(monkeypatch):
     assert r["all_cores"]["cores"] == 2 and r["all_cores"]["value"] > 0
     n = bench.cpu_baseline_nnet(seconds_target=0.1)
     assert n["kind"] == "reference" and n["value"] > 0 and n["all_cores"]["value"] > 0
+
+
+@pytest.mark.parametrize("name,cfg,mseed,fseed,rows", [
+    ("swbd_tri4_10k", "swbd_tri4", 777, 779, 24), ("wsj_tri4b_4k", "wsj_tri4b", 777, 780, 64)])
+def test_oracle_vs_full_size_reference_summaries(name, cfg, mseed, fseed, rows):
+    """The restatement on a sample of the frames of the full-size fixtures (per-frame summaries of
+    what the real reference computed, tests/golden/make_golden_swbd.py)."""
+    g = np.load(gpath(name + ".npz"))
+    D, P, G = synth.GMM_CONFIGS[cfg]
+    m = synth.make_gmm(D, P, G, seed=mseed)
+    T = len(g["argmax"])
+    feats = synth.make_feats(m, T, seed=fseed)
+    pick = np.linspace(0, T - 1, rows).astype(int)
+    got, _, _ = gmm_oracle(m, feats[pick])
+    r = np.arange(rows)
+    assert np.abs(got[r, g["argmax"][pick]] - g["best"][pick]).max() <= 2e-5
+    assert np.abs(got[:, g["pdf_cols"]] - g["cols"][pick]).max() <= 2e-5
+    assert np.abs(got.astype(np.float64).sum(1) - g["rowsum"][pick]).max() / P <= 1e-5
+    near_tie = g["best"][pick] - g["second"][pick] < 1e-4
+    assert ((got.argmax(1) == g["argmax"][pick]) | near_tie).all()
