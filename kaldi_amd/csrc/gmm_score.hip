@@ -668,7 +668,8 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #ifdef AMLIKE_DIFF_STAMPS
 // Diagnostic build only: cycles (s_memtime) that each wave of one interior block spent in its
 // register passes, in its tails and in total: [wave][0..3] = pass, tail, total, tiles.
-__device__ unsigned long long g_diff_stamps[8 * 4];
+__device__ unsigned long long g_diff_stamps[8 * 6];
+__device__ unsigned long long g_diff_blocks[256 * 4];  // per frame chunk: entry time, duration (10 ns), ticks, XCC id
 #define AMLIKE_STAMP() __builtin_readcyclecounter()
 #endif
 // AMLIKE_DIFF_PRIO 1: a wave in its pass gets issue priority over a wave in its tail; 3: the
@@ -688,6 +689,9 @@ __device__ unsigned long long g_diff_stamps[8 * 4];
 #endif
 #ifndef AMLIKE_DIFF_STAGGER
 #define AMLIKE_DIFF_STAGGER 1
+#endif
+#ifndef AMLIKE_DIFF_EARLYLOAD
+#define AMLIKE_DIFF_EARLYLOAD 1
 #endif
 #ifndef AMLIKE_DIFF_FASTTAIL
 #define AMLIKE_DIFF_FASTTAIL 1
@@ -712,6 +716,9 @@ __global__ void __launch_bounds__(64 * W, OCC)
   // whichever 32-Gaussian tile it belongs to.
   typedef float accvec __attribute__((ext_vector_type(kSteps)));
   if (guard_skips(ar.ctl, ar.fix_cap, ar.guard)) return;
+#ifdef AMLIKE_DIFF_STAMPS
+  const unsigned long long real_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   int bx, by;
   {
     const int total = gridDim.x, L = blockIdx.x;
@@ -811,7 +818,6 @@ __global__ void __launch_bounds__(64 * W, OCC)
   if (ntile == 0) return;
 
   constexpr int kMfma = KS * NPROD * NT;
-  constexpr int kSkip = 2;
   // Feature fragments are requested from LDS kPre k-steps before the matrix instructions
   // that read them (a wave that waits on LDS issues nothing, its matrix work included).
   constexpr int kPre = AMLIKE_DIFF_PRE < KS ? AMLIKE_DIFF_PRE : (KS > 1 ? KS - 1 : 1);
@@ -904,39 +910,60 @@ __global__ void __launch_bounds__(64 * W, OCC)
   auto tile_ptr = [&](int fn) { return s_b + (((fn / FTB) & 1) * FTB + fn % FTB) * kTileU4 + lane; };
 
 #ifdef AMLIKE_DIFF_STAMPS
-  unsigned long long stamp_pass = 0, stamp_tail = 0, stamp_tiles = 0;
+  unsigned long long stamp_pass = 0, stamp_tail = 0, stamp_tiles = 0, stamp_vm = 0, stamp_bar = 0;
   const unsigned long long stamp_begin = AMLIKE_STAMP();
+  const unsigned long long real_begin = __builtin_amdgcn_s_memrealtime();  // 100 MHz
   auto stamps_out = [&]() {
-    if (bx == ar.nbx / 2 && by == 1 && lane == 0) {
-      g_diff_stamps[w * 4 + 0] = stamp_pass;
-      g_diff_stamps[w * 4 + 1] = stamp_tail;
-      g_diff_stamps[w * 4 + 2] = AMLIKE_STAMP() - stamp_begin;
-      g_diff_stamps[w * 4 + 3] = stamp_tiles;
+    if (bx == ar.nbx / 2 && by == (int)(gridDim.x / ar.nbx) / 2 && lane == 0) {
+      g_diff_stamps[w * 5 + 0] = stamp_pass;
+      g_diff_stamps[w * 5 + 1] = stamp_tail;
+      g_diff_stamps[w * 5 + 2] = AMLIKE_STAMP() - stamp_begin;
+      g_diff_stamps[w * 5 + 3] = stamp_tiles;
+      g_diff_stamps[w * 5 + 4] = __builtin_amdgcn_s_memrealtime() - real_begin;
+      g_diff_stamps[40 + w] = (stamp_vm << 32) | stamp_bar;
+    }
+    if (bx == ar.nbx / 2 && by < 256 && lane == 0 && w == 0) {
+      g_diff_blocks[by * 4 + 0] = real_entry;
+      g_diff_blocks[by * 4 + 1] = __builtin_amdgcn_s_memrealtime() - real_entry;
+      g_diff_blocks[by * 4 + 2] = AMLIKE_STAMP() - stamp_begin;
+      g_diff_blocks[by * 4 + 3] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
     }
   };
 #endif
 
   // The register pass of frame tile ft: the running sums of its scores (acc_c) on the vector
-  // unit, with the matrix instructions of tile ft+1 (into acc_n) issued between them.
-  // preloaded: the feature fragments of the first kPre k-steps (and the gconsts, where they
-  // come from LDS) are already on their way.
-  accvec sv;
-  auto pass = [&](const int ft, accvec &acc_c, accvec &acc_n, auto preloaded_tag) __attribute__((always_inline)) {
-    constexpr bool preloaded = decltype(preloaded_tag)::value;
-    const uint4 *bt = tile_ptr(ft + 1);
-    if (!preloaded) {
-      load_gc(acc_n);
-      if (!(ABL & 8)) load_b_head(bt);
+  // unit, with the matrix instructions of tile ft+1 (into acc_n) issued between them.  The
+  // feature fragments of the first kPre k-steps (and the gconsts, where they come from LDS)
+  // have been requested by the caller (preload), as early as the staging protocol allows.
+  auto report_overflow = [&](int row, int col) {
+    const int kk = atomicAdd(ar.ctl, 1);
+    if (kk < ar.fix_cap) ar.fix_list[kk] = make_int2(row, col);
+  };
+
+  // Stores value v of this lane for the frame tile that starts at frame t0 (voff: the lane's entry
+  // of s_voff); a value out of range goes to the repair list.
+  auto emit_at = [&](const int t0, float v, uint32_t voff) __attribute__((always_inline)) {
+    char *tile_base = reinterpret_cast<char *>(ar.out) + (size_t)t0 * (size_t)ar.ldo * sizeof(float);
+    if (voff != ~0u) {
+      if (!(ABL & 1)) *reinterpret_cast<float *>(tile_base + voff) = v;
+      if (!ABL && !(fabsf(v) <= kMaxAbsLogLike))
+        report_overflow(t0 + j, (int)(voff / 4u - (uint32_t)j * (uint32_t)ar.ldo));
     }
+  };
+  accvec sv;
+  auto pass = [&](const int ft, accvec &acc_c, accvec &acc_n) __attribute__((always_inline)) {
+    const uint4 *bt = tile_ptr(ft + 1);
     float s_ = 0.0f;
 #ifdef AMLIKE_DIFF_STAMPS
     const unsigned long long st0 = AMLIKE_STAMP();
 #endif
 #if AMLIKE_DIFF_PRIO == 1
     __builtin_amdgcn_s_setprio(2);
+#elif AMLIKE_DIFF_PRIO == 4
+    if (w >= W / 2) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(2);
 #endif
-    // Leading steps without matrix work cover the LDS latency of the first fragments.
-    constexpr int skip = preloaded ? 0 : kSkip;
+    constexpr int skip = 0;
     // exp of step st+1 is issued before the fma of step st consumes the exp of step st: no
     // instruction waits on the result of the transcendental instruction just before it.
     float e_cur = (ABL & 2) ? 0.0f : fast_exp2(acc_c[0]);
@@ -964,16 +991,14 @@ __global__ void __launch_bounds__(64 * W, OCC)
     }
 #if AMLIKE_DIFF_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
+#elif AMLIKE_DIFF_PRIO == 4
+    if (w >= W / 2) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
 #endif
 #ifdef AMLIKE_DIFF_STAMPS
     stamp_pass += AMLIKE_STAMP() - st0;
     ++stamp_tiles;
 #endif
-  };
-
-  auto report_overflow = [&](int row, int col) {
-    const int kk = atomicAdd(ar.ctl, 1);
-    if (kk < ar.fix_cap) ar.fix_list[kk] = make_int2(row, col);
   };
 
   // General tail: the segments of this wave's chunk for frame tile ft, two per iteration:
@@ -1022,7 +1047,6 @@ __global__ void __launch_bounds__(64 * W, OCC)
   // endw, output offsets from s_voff, stores relative to the tile's first output row.
   auto tail_fast = [&](const int ft, const accvec &acc_c) __attribute__((always_inline)) {
     const int t0 = t_begin + (ft << 5);
-    char *tile_base = reinterpret_cast<char *>(ar.out) + (size_t)t0 * (size_t)ar.ldo * sizeof(float);
     // Keep the packed words opaque per tile: the field extraction (scalar unit, cheap) is redone
     // every tile instead of every field living in a scalar register of its own.
 #if __HIP_DEVICE_COMPILE__
@@ -1030,21 +1054,19 @@ __global__ void __launch_bounds__(64 * W, OCC)
     for (int q = 0; q < (kMaxPairs + 2) / 3; ++q) asm volatile("" : "+s"(endw[q]));
 #endif
     auto end_of = [&](int seg) -> int { return (endw[seg / 6] >> (5 * (seg % 6))) & 31; };
-    auto finish = [&](int end_a, int end_b, int start_a, int start_b) -> float {
+    auto gather = [&](int end_a, int end_b, int start_a, int start_b, float &s01, float &ref, float &x) {
       const auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(sv[end_a]),
                                                        __float_as_uint(sv[end_b]), false, false);
       const auto xx = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_c[start_a]),
                                                        __float_as_uint(acc_c[start_b]), false, false);
-      const float S = (1.0f + fast_exp2(__uint_as_float(xx[1]))) +
-                      (__uint_as_float(ss[0]) + __uint_as_float(ss[1]));
-      return fmaf(fast_log2(S), kLn2, __uint_as_float(xx[0]));
+      s01 = __uint_as_float(ss[0]) + __uint_as_float(ss[1]);
+      ref = __uint_as_float(xx[0]);
+      x = __uint_as_float(xx[1]);
     };
-    auto emit = [&](float v, uint32_t voff) {
-      if (voff != ~0u) {
-        if (!(ABL & 1)) *reinterpret_cast<float *>(tile_base + voff) = v;
-        if (!ABL && !(fabsf(v) <= kMaxAbsLogLike))
-          report_overflow(t0 + j, (int)(voff / 4u - (uint32_t)j * (uint32_t)ar.ldo));
-      }
+    auto finish = [&](int end_a, int end_b, int start_a, int start_b) -> float {
+      float s01, ref, x;
+      gather(end_a, end_b, start_a, start_b, s01, ref, x);
+      return fmaf(fast_log2((1.0f + fast_exp2(x)) + s01), kLn2, ref);
     };
 #pragma unroll
     for (int kk = 0; kk < (kMaxPairs + 1) / 2; ++kk) {
@@ -1052,22 +1074,17 @@ __global__ void __launch_bounds__(64 * W, OCC)
       const int ea0 = end_of(4 * kk), eb0 = end_of(4 * kk + 1);
       const int sa0 = kk == 0 ? 0 : min(end_of(4 * kk - 1) + 1, kSteps - 1);
       const int sb0 = min(ea0 + 1, kSteps - 1);
+      const int ea1 = end_of(4 * kk + 2), eb1 = end_of(4 * kk + 3);
+      const int sa1 = min(eb0 + 1, kSteps - 1), sb1 = min(ea1 + 1, kSteps - 1);
       const uint32_t voff0 = s_voff[(2 * kk) * 64 + lane];
+      const uint32_t voff1 = s_voff[(2 * kk + 1) * 64 + lane];
       float v0 = finish(ea0, eb0, sa0, sb0);
-      if (2 * kk + 1 < kMaxPairs) {
-        const int ea1 = end_of(4 * kk + 2), eb1 = end_of(4 * kk + 3);
-        const int sa1 = min(eb0 + 1, kSteps - 1), sb1 = min(ea1 + 1, kSteps - 1);
-        const uint32_t voff1 = s_voff[(2 * kk + 1) * 64 + lane];
-        float v1 = finish(ea1, eb1, sa1, sb1);
-        // both values exist before either store's control flow starts
-        pin_order(v0);
-        pin_order(v1);
-        emit(v0, voff0);
-        emit(v1, voff1);
-      } else {
-        pin_order(v0);
-        emit(v0, voff0);
-      }
+      float v1 = finish(ea1, eb1, sa1, sb1);
+      // both values exist before either store's control flow starts
+      pin_order(v0);
+      pin_order(v1);
+      emit_at(t0, v0, voff0);
+      emit_at(t0, v1, voff1);
     }
   };
 
@@ -1094,6 +1111,13 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #endif
   };
 
+  // What a pass needs first: the feature fragments of the first k-steps of tile fn and, where
+  // they come from LDS, the gconsts in the accumulators the pass writes.
+  auto preload = [&](const int fn, accvec &acc) __attribute__((always_inline)) {
+    load_gc(acc);
+    if (!(ABL & 8)) load_b_head(tile_ptr(fn));
+  };
+
   if (AMLIKE_DIFF_PP && W == 8 && !(ABL & 16)) {
     // Ping-pong.  The two waves that share a SIMD (w and w + 4) alternate: while one is in its
     // register pass and owns the matrix pipe, the other finishes the segments of its previous
@@ -1106,17 +1130,17 @@ __global__ void __launch_bounds__(64 * W, OCC)
     constexpr int PB = 2 * FTB;  // phases per staged group
     auto phase_sync = [&](const int p) __attribute__((always_inline)) {
       if ((p + 3) % PB == 0) wait_vector_memory();  // this wave's share of the next group has landed
+#ifdef AMLIKE_DIFF_STAMPS
+      const unsigned long long sb0 = AMLIKE_STAMP();
+#endif
       __syncthreads();
+#ifdef AMLIKE_DIFF_STAMPS
+      stamp_bar += AMLIKE_STAMP() - sb0;
+#endif
       if ((p + 2) % PB == 0) {
         const int G = (p + 2) / PB;
         if (G + 1 < ngroup) stage(G + 1);
       }
-    };
-    // What the next pass needs first, requested before the barrier in front of it: the feature
-    // fragments of the first k-steps of tile fn and the gconsts in the accumulators it writes.
-    auto preload = [&](const int fn, accvec &acc) __attribute__((always_inline)) {
-      load_gc(acc);
-      if (!(ABL & 8)) load_b_head(tile_ptr(fn));
     };
     auto tail_if = [&](const int ft, const accvec &acc) __attribute__((always_inline)) {
       if (ft < ntile) tail(ft, acc);
@@ -1126,12 +1150,12 @@ __global__ void __launch_bounds__(64 * W, OCC)
       preload(1, acc_alt);
       for (int m = 0; m < npairs; ++m) {
         if (m > 0) phase_sync(4 * m);
-        pass(2 * m, acc_cur, acc_alt, std::true_type());
+        pass(2 * m, acc_cur, acc_alt);
         phase_sync(4 * m + 1);
         tail_if(2 * m, acc_cur);
         preload(2 * m + 2, acc_cur);
         phase_sync(4 * m + 2);
-        pass(2 * m + 1, acc_alt, acc_cur, std::true_type());
+        pass(2 * m + 1, acc_alt, acc_cur);
         phase_sync(4 * m + 3);
         tail_if(2 * m + 1, acc_alt);
         preload(2 * m + 3, acc_alt);
@@ -1144,12 +1168,12 @@ __global__ void __launch_bounds__(64 * W, OCC)
         }
         preload(2 * m + 1, acc_alt);
         phase_sync(4 * m + 1);
-        pass(2 * m, acc_cur, acc_alt, std::true_type());
+        pass(2 * m, acc_cur, acc_alt);
         phase_sync(4 * m + 2);
         tail_if(2 * m, acc_cur);
         preload(2 * m + 2, acc_cur);
         phase_sync(4 * m + 3);
-        pass(2 * m + 1, acc_alt, acc_cur, std::true_type());
+        pass(2 * m + 1, acc_alt, acc_cur);
       }
       tail_if(2 * npairs - 1, acc_alt);
     }
@@ -1170,20 +1194,40 @@ __global__ void __launch_bounds__(64 * W, OCC)
   // tile the first half never starts, and with one tile per group there is no room to shift.)
   const bool late_half = AMLIKE_DIFF_STAGGER && W == 8 && FTB >= 2 && w >= W / 2;
   auto group_barrier = [&](const int g) __attribute__((always_inline)) {
+#ifdef AMLIKE_DIFF_STAMPS
+    const unsigned long long sb0 = AMLIKE_STAMP();
+#endif
     __syncthreads();
+#ifdef AMLIKE_DIFF_STAMPS
+    stamp_bar += AMLIKE_STAMP() - sb0;
+#endif
     if (g + 1 < ngroup) stage(g + 1);
   };
+  // The first fragments of a pass are requested before the tail in front of it whenever their
+  // tile has been published by then (always for the second half; for the first half unless the
+  // tile opens a group), otherwise right before the pass.
+  bool requested = false;
   auto tile_body = [&](const int ft, accvec &a_cur, accvec &a_next) __attribute__((always_inline)) {
     const int fn = ft + 1;
     if (fn % FTB == 0 && !(ABL & 16) && !late_half) group_barrier(fn / FTB);
-    pass(ft, a_cur, a_next, std::false_type());
+    load_gc(a_next);
+    if (!requested && !(ABL & 8)) load_b_head(tile_ptr(fn));
+    pass(ft, a_cur, a_next);
     // The barrier publishes a staged group: see this wave's staging loads (issued FTB tiles ago)
     // complete here, before this tile's stores join the queue, rather than at the barrier
     // itself, where the wait would also cover those stores.
     if ((ft + 2) % FTB == 0 && !(ABL & 16)) {
+#ifdef AMLIKE_DIFF_STAMPS
+      const unsigned long long sv0 = AMLIKE_STAMP();
+#endif
       wait_vector_memory();
+#ifdef AMLIKE_DIFF_STAMPS
+      stamp_vm += AMLIKE_STAMP() - sv0;
+#endif
       if (late_half && ft + 1 < ntile) group_barrier((ft + 2) / FTB);
     }
+    requested = AMLIKE_DIFF_EARLYLOAD && (late_half || (ft + 2) % FTB != 0);
+    if (requested && !(ABL & 8)) load_b_head(tile_ptr(ft + 2));
     tail(ft, a_cur);
   };
   for (int ft = 0; ft < ntile; ft += 2) {
@@ -2722,12 +2766,27 @@ int amlike_gmm_time_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, 
   *ms_per_launch = ms / iters;
 #ifdef AMLIKE_DIFF_STAMPS
   {
-    unsigned long long hs[8 * 4];
+    {
+      unsigned long long hb[256 * 4];
+      if (hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_diff_blocks), sizeof(hb)) == hipSuccess) {
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < 256; ++b)
+          if (hb[b * 4 + 1]) t0 = std::min(t0, hb[b * 4]);
+        for (int b = 0; b < 256; ++b)
+          if (hb[b * 4 + 1])
+            fprintf(stderr, "chunk %3d: start %8.2f us  duration %7.2f us  loop ticks %llu  xcc %llu\n", b,
+                    (hb[b * 4] - t0) * 0.01, hb[b * 4 + 1] * 0.01, hb[b * 4 + 2], hb[b * 4 + 3]);
+      }
+    }
+    unsigned long long hs[8 * 6];
     if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_diff_stamps), sizeof(hs)) == hipSuccess)
       for (int wv = 0; wv < 8; ++wv) {
-        const double n = (double)std::max(1ull, hs[wv * 4 + 3]);
-        fprintf(stderr, "stamps wave %d: tiles %llu  pass %.0f  tail %.0f  total/tile %.0f (cycle-counter ticks)\n",
-                wv, hs[wv * 4 + 3], hs[wv * 4] / n, hs[wv * 4 + 1] / n, hs[wv * 4 + 2] / n);
+        const double n = (double)std::max(1ull, hs[wv * 5 + 3]);
+        fprintf(stderr, "stamps wave %d: tiles %llu  pass %.0f  tail %.0f  total/tile %.0f ticks; %.2f ticks per ns\n",
+                wv, hs[wv * 5 + 3], hs[wv * 5] / n, hs[wv * 5 + 1] / n, hs[wv * 5 + 2] / n,
+                (double)hs[wv * 5 + 2] / (10.0 * (double)std::max(1ull, hs[wv * 5 + 4])));
+        fprintf(stderr, "   per tile: vmcnt wait %.0f, barrier wait %.0f ticks\n", (double)(hs[40 + wv] >> 32) / n,
+                (double)(hs[40 + wv] & 0xffffffffull) / n);
       }
   }
 #endif
