@@ -123,6 +123,21 @@ int amlike_gmm_score_dev(amlike_gmm_t *gmm, const float *d_feats, int32_t T, int
                          int32_t feat_dim, float log_sum_exp_prune, float *d_out,
                          int32_t ldo, void *stream);
 
+/* amlike_gmm_score_dev for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
+ * reference.  Same arguments and results as amlike_gmm_score_dev without pruning
+ * (log_sum_exp_prune <= 0), but the scratch memory of the launch (operand images of the
+ * features, the repair list, partial sums of split pdfs) comes from an array built into the
+ * library, amlike_gmm_noalloc_scratch_bytes() (8 MiB) per GPU, instead of the handle's
+ * growable buffers: the call allocates nothing, and returns AMLIKE_EINVAL when T frames of this
+ * model need more than that (the swbd tri4 shape: up to about 6 000 frames per call), for models
+ * the fused kernels do not cover (dimension above 64), and before amlike_init.  Every call on a
+ * GPU uses that GPU's one array: calls that overlap in time on one GPU, from any handle or
+ * stream, race; issue them on one stream or order them yourself. */
+int amlike_gmm_score_dev_noalloc(amlike_gmm_t *gmm, const float *d_feats, int32_t T, int32_t ld,
+                                 int32_t feat_dim, float *d_out, int32_t ldo, void *stream);
+size_t amlike_gmm_noalloc_scratch_bytes(void);
+
 /* Waits for `stream` and returns AMLIKE_OK or AMLIKE_ENONFINITE for the
  * launches since the previous poll. */
 int amlike_gmm_poll(amlike_gmm_t *gmm, void *stream);

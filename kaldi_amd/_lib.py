@@ -58,6 +58,8 @@ def _declare(lib):
         "amlike_gmm_num_gauss": (c_int32, [c_void_p]),
         "amlike_gmm_dim": (c_int32, [c_void_p]),
         "amlike_gmm_score": (ctypes.c_int, [c_void_p, fp, c_int32, c_int32, c_int32, c_float, fp, c_int32]),
+        "amlike_gmm_score_dev_noalloc": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+        "amlike_gmm_noalloc_scratch_bytes": (ctypes.c_size_t, []),
         "amlike_gmm_score_dev": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p]),
         "amlike_gmm_poll": (ctypes.c_int, [c_void_p, c_void_p]),
         "amlike_gmm_gauss_loglikes": (ctypes.c_int, [c_void_p, c_int32, c_int32, fp, c_int32, c_int32, c_int32, fp, c_int32]),

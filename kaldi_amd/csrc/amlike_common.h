@@ -25,6 +25,9 @@ int NumComputeUnits();
 // is per thread and starts at 0, so a thread other than the one that called amlike_init would
 // otherwise work on the wrong GPU.  No-op before amlike_init.
 int BindThread();
+// Looks up, once per device, the address of the built-in scratch array of the entry point that
+// allocates nothing (gmm_score.hip); called by amlike_init with `device` current.
+int SetupNoAllocScratch(int device);
 
 // Growable device buffer owned by a handle.  Never shrinks.
 struct DeviceBuffer {

@@ -253,6 +253,7 @@ int amlike_init(int device) {
                      device, prop.gcnArchName);
     return AMLIKE_ENODEV;
   }
+  if (int rc = amlike::SetupNoAllocScratch(device)) return rc;
   amlike::g_device = device;
   amlike::g_num_cu = prop.multiProcessorCount;
   return AMLIKE_OK;

@@ -1617,6 +1617,32 @@ struct Piece {
 
 using namespace amlike;
 
+// Built-in scratch memory of amlike_gmm_score_dev_noalloc: one array per GPU the library runs
+// on, held until the process ends.  In host code the name is a stand-in, not a device address;
+// SetupNoAllocScratch asks the runtime for the address on the current device once and
+// everything else uses that pointer.
+constexpr size_t kNoAllocScratchBytes = (size_t)8 << 20;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+constexpr int kMaxDevices = 64;
+static unsigned char *g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mu;
+
+namespace amlike {
+int SetupNoAllocScratch(int device) {
+  if (device < 0 || device >= kMaxDevices) {
+    SetError("amlike_init: device index %d beyond the %d this library keeps scratch memory for", device,
+             kMaxDevices);
+    return AMLIKE_EINVAL;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[device]) return AMLIKE_OK;
+  void *ptr = nullptr;
+  AMLIKE_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));  // the calling thread's current device
+  g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+  return AMLIKE_OK;
+}
+}  // namespace amlike
+
 struct amlike_gmm {
   int32_t num_pdfs = 0, num_gauss = 0, dim = 0;
   int device = 0;
@@ -2039,9 +2065,33 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
 }
 
 // Launches the scoring kernels for [T x dim] device features with conforming layout.
+// Scratch memory of one launch comes from the handle's growable buffers, or, when `arena` is
+// given, from that fixed region (nothing is allocated; AMLIKE_EINVAL if it is too small).
+struct ScratchArena {
+  unsigned char *base;
+  size_t bytes, used;
+};
+
 static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float *d_out, int ldo,
-                       hipStream_t stream) {
+                       hipStream_t stream, ScratchArena *arena = nullptr) {
   const Variant &v = *g->variant;
+  // bytes from the arena, or from the handle's buffer `ws`
+  auto take = [&](DeviceBuffer *ws, size_t bytes, void **out) -> int {
+    if (!arena) {
+      int rc = ws->Reserve(bytes);
+      *out = ws->ptr;
+      return rc;
+    }
+    const size_t at = (arena->used + 255) & ~(size_t)255;
+    if (at + bytes > arena->bytes) {
+      SetError("amlike_gmm_score_dev_noalloc: %d frames of this model need more than the %zu bytes of "
+               "built-in scratch memory", T, arena->bytes);
+      return AMLIKE_EINVAL;
+    }
+    *out = arena->base + at;
+    arena->used = at + bytes;
+    return AMLIKE_OK;
+  };
   const int nbx = g->num_wc / v.W;
   // Frames per block: few enough blocks that the one-off load of the model
   // operands (NT*D registers per lane) is amortised over many frame tiles, enough
@@ -2091,9 +2141,10 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
   ar.guard = 0;
   if (g->num_partials > 0) {
     const int part_ld = (T + 31) & ~31;
-    int rc = g->ws_part.Reserve((size_t)2 * g->num_partials * part_ld * sizeof(float));
+    void *part = nullptr;
+    int rc = take(&g->ws_part, (size_t)2 * g->num_partials * part_ld * sizeof(float), &part);
     if (rc != AMLIKE_OK) return rc;
-    ar.part_m = static_cast<float *>(g->ws_part.ptr);
+    ar.part_m = static_cast<float *>(part);
     ar.part_s = ar.part_m + (size_t)g->num_partials * part_ld;
     ar.part_ld = part_ld;
   }
@@ -2107,12 +2158,13 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
     if (expand) {
       // fp32 [T x dim] -> operand tiles (160 B per frame, part and k-step).
       const size_t tile_bytes = (size_t)KS * parts * 64 * 16;
-      int rc = ws->Reserve((size_t)num_ftiles * tile_bytes);
+      void *image = nullptr;
+      int rc = take(ws, (size_t)num_ftiles * tile_bytes, &image);
       if (rc != AMLIKE_OK) return rc;
-      a.bx = static_cast<const uint4 *>(ws->ptr);
+      a.bx = static_cast<const uint4 *>(image);
       const int threads = num_ftiles * KS * 64;
       hipLaunchKernelGGL(expand, dim3((threads + 255) / 256), dim3(256), 0, stream, d_feats, T, ld,
-                         g->dim, static_cast<uint4 *>(ws->ptr), num_ftiles, g->d_bscale, g->d_ctl,
+                         g->dim, static_cast<uint4 *>(image), num_ftiles, g->d_bscale, g->d_ctl,
                          a.fix_cap, guard == 2 ? 2 : 0);
       AMLIKE_HIP(hipGetLastError());
       smem = 2 * FramesTilesPerBarrier(v.W, KS, parts) * tile_bytes + (size_t)v.W * v.NT * 32 * 4 +
@@ -2141,10 +2193,12 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
     // Differenced pass, exact repair of the few pairs whose sum overflowed, and a full pass of
     // the wide-range kernel that runs only when the first pass could not be used (decided on
     // the device: features outside the fp16 range, or more overflows than the list holds).
-    const size_t cap = std::max<size_t>(4096, std::min<size_t>((size_t)1 << 21, (size_t)T * g->num_pdfs / 256));
-    int rc = g->ws_fix.Reserve(cap * sizeof(int2));
+    const size_t cap = std::max<size_t>(4096, std::min<size_t>(arena ? (size_t)1 << 14 : (size_t)1 << 21,
+                                                              (size_t)T * g->num_pdfs / 256));
+    void *fix = nullptr;
+    int rc = take(&g->ws_fix, cap * sizeof(int2), &fix);
     if (rc != AMLIKE_OK) return rc;
-    ar.fix_list = static_cast<int2 *>(g->ws_fix.ptr);
+    ar.fix_list = static_cast<int2 *>(fix);
     ar.fix_cap = (int)cap;
     AMLIKE_HIP(hipMemsetAsync(g->d_ctl, 0, 2 * sizeof(int), stream));
     rc = pass(v.kernel, v.expand, v.prec ? 2 : 3, g->d_apack, g->d_gcpack, &g->ws_expand, 1);
@@ -2162,6 +2216,7 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
     int rc = pass(v.kernel, v.mode >= 1 ? v.expand : nullptr, 3, g->d_apack, g->d_gcpack, &g->ws_expand, 0);
     if (rc != AMLIKE_OK) return rc;
   }
+  if (arena) return AMLIKE_OK;  // (the description below is a heap-allocated string)
   char buf[256];
   snprintf(buf, sizeof(buf), "%s grid=%d block=%d frames_per_block=%d wave_chunks=%d fill=%.4f splits=%d",
            v.name, nbx * nby, 64 * v.W, fpb, g->num_wc, g->fill, g->num_splits);
@@ -2363,6 +2418,27 @@ int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32
   }
   return LaunchScore(g, use, T, use_ld, d_out, ldo, st);
 }
+
+int amlike_gmm_score_dev_noalloc(amlike_gmm_t *g, const float *d_feats, int32_t T, int32_t ld,
+                                 int32_t feat_dim, float *d_out, int32_t ldo, void *stream) {
+  if (int brc = BindThread()) return brc;
+  int rc = CheckScoreArgs(g, T, ld, feat_dim, ldo, d_feats, d_out);
+  if (rc != AMLIKE_OK) return rc;
+  if (!g->variant || g->variant->mode == 0) {
+    SetError("amlike_gmm_score_dev_noalloc: this model is not scored by a fused 16-bit kernel (dimension above "
+             "64, or the exact-fp32 mode); use amlike_gmm_score_dev");
+    return AMLIKE_EINVAL;
+  }
+  unsigned char *base = g->device >= 0 && g->device < kMaxDevices ? g_scratch_ptr[g->device] : nullptr;
+  if (!base) {
+    SetError("amlike_gmm_score_dev_noalloc: amlike_init has not set up device %d", g->device);
+    return AMLIKE_EINVAL;
+  }
+  ScratchArena arena{base, kNoAllocScratchBytes, 0};
+  return LaunchScore(g, d_feats, T, ld, d_out, ldo, static_cast<hipStream_t>(stream), &arena);
+}
+
+size_t amlike_gmm_noalloc_scratch_bytes(void) { return kNoAllocScratchBytes; }
 
 int amlike_gmm_poll(amlike_gmm_t *g, void *stream) {
   if (int brc = BindThread()) return brc;

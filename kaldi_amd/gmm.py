@@ -118,6 +118,11 @@ class AmDiagGmm:
                                                    float(log_sum_exp_prune), c_void_p(d_out_ptr),
                                                    ldo, c_void_p(stream or 0)))
 
+    def LogLikelihoodsDeviceNoAlloc(self, d_feats_ptr, T, ld, D, d_out_ptr, ldo, stream=None):
+        """Device-pointer form that allocates nothing (scratch memory built into the library)."""
+        _lib.check(_lib.lib().amlike_gmm_score_dev_noalloc(self._h, c_void_p(d_feats_ptr), T, ld, D,
+                                                           c_void_p(d_out_ptr), ldo, c_void_p(stream or 0)))
+
     def Poll(self, stream=None):
         _lib.check(_lib.lib().amlike_gmm_poll(self._h, c_void_p(stream or 0)))
 
