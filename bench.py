@@ -15,7 +15,13 @@ data-path collective.  After the timed region the ranks all-reduce (RCCL)
 {sum of best-pdf log-likelihood, frames}, the analogue of the summary the
 reference binaries log.
 
+With --gpus N > 1 and no torch.distributed environment, the script starts the
+torch.distributed.run form itself as a child process and relays its line and exit code.
+
 The line also carries
+  host_to_host  the same scoring through host pointers (amlike_gmm_score_submit / _wait, two
+                submissions in flight, page-locked buffers): features up and the dense
+                [T x P] result down over PCIe -- the rate a caller holding host matrices sees;
   roofline      dominant kernel's algorithmic FLOP / its mean duration, measured with HIP
                 events around that kernel in every timed step (on the launch stream), against
                 the 16-bit matrix peak divided by the partial products one fp32-grade product
@@ -29,6 +35,7 @@ The line also carries
 import argparse
 import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
@@ -57,7 +64,19 @@ F16X2_PRODUCTS = 3
 # the chip sustains under the matrix pipe depends on the switching activity of the data)
 MEASURED_F16_MFMA_TFLOPS = 2419.0
 MEASURED_F16_MFMA_TFLOPS_RANDOM = 1700.0
-PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 3246530.0, 8875470.0
+# (profiles/r2_*_pmc_summary.txt: the current kernel)
+PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 3365560.0, 8428920.0
+PMC_SOURCE = "profiles/r2_a_gmm_diff_pmc_summary.txt"
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def _cpu_workers():
@@ -109,7 +128,7 @@ def cpu_baseline_gmm(model, gconsts, dim, seconds_target=30.0):
 
         fps1, secs1, fps_all, secs_all = _ref_rates(
             oracle, make_args, lambda w: [("sample%d" % w, synth.make_feats(model, n, seed=778 + w))], n, workers)
-        return {"value": fps1, "unit": "frames/s", "cores": 1, "kind": "reference",
+        return {"value": fps1, "unit": "frames/s", "cores": 1, "kind": "reference", "cpu": _cpu_model(),
                 "sample": "%d frames of the same synthetic workload, gmm-compute-likes loop, 1 thread, %.1f s"
                           % (n, secs1),
                 "all_cores": {"value": fps_all, "unit": "frames/s", "cores": workers,
@@ -120,7 +139,7 @@ def cpu_baseline_gmm(model, gconsts, dim, seconds_target=30.0):
     oracle.gmm_compute_likes(gconsts, model["means_invvars"], model["inv_vars"],
                              model["pdf_offsets"], feats)
     secs = time.time() - t0
-    return {"value": n / secs, "unit": "frames/s", "cores": 1, "kind": "port",
+    return {"value": n / secs, "unit": "frames/s", "cores": 1, "kind": "port", "cpu": _cpu_model(),
             "sample": "%d frames of the same synthetic workload, gmm-compute-likes loop, 1 thread, %.1f s" % (n, secs)}
 
 
@@ -150,7 +169,7 @@ def cpu_baseline_nnet(seconds_target=8.0):
         return [("utt%d" % i, rng.normal(size=(int(t), 40)).astype(np.float32)) for i, t in enumerate(lengths)]
 
     fps1, secs1, fps_all, secs_all = _ref_rates(oracle, make_args, items_for, n, workers)
-    return {"value": fps1, "unit": "frames/s", "cores": 1, "kind": "reference",
+    return {"value": fps1, "unit": "frames/s", "cores": 1, "kind": "reference", "cpu": _cpu_model(),
             "sample": "%d frames in %d utterances, NnetComputation + log-likelihood conversion, 1 thread, %.1f s"
                       % (n, len(lengths), secs1),
             "all_cores": {"value": fps_all, "unit": "frames/s", "cores": workers,
@@ -158,18 +177,63 @@ def cpu_baseline_nnet(seconds_target=8.0):
                                     % (workers, n, secs_all)}}
 
 
+def host_to_host_rate(am, feats, P, chunk_frames=32768):
+    """Frames/s through host pointers: amlike_gmm_score_submit / _wait with two submissions in
+    flight over chunks of the rank's frames, features and results in page-locked host memory."""
+    T, D = feats.shape[0], am.Dim()
+    chunk = int(min(chunk_frames, T, (1 << 30) // P))
+    fin = [_lib.PinnedArray(chunk, D) for _ in range(2)]
+    fout = [_lib.PinnedArray(chunk, P) for _ in range(2)]
+    starts = list(range(0, T, chunk))
+
+    def run():
+        tickets = [None, None]
+        for i, t0 in enumerate(starts):
+            k = i & 1
+            if tickets[k] is not None:
+                am.Wait(tickets[k])
+            n = min(chunk, T - t0)
+            fin[k].a[:n] = feats[t0:t0 + n, :D]
+            tickets[k] = am.Submit(fin[k].a[:n], fout[k].a[:n])
+        for t in tickets:
+            if t is not None:
+                am.Wait(t)
+
+    run()  # buffers and the handle's device slots get their size
+    t0 = time.perf_counter()
+    run()
+    secs = time.perf_counter() - t0
+    for b in fin + fout:
+        b.close()
+    return {"value": T / secs, "unit": "frames/s", "seconds": secs, "frames": T,
+            "bytes_over_pcie": 4.0 * T * (P + D),
+            "how": "amlike_gmm_score_submit/_wait, two submissions in flight, chunks of %d frames, page-locked "
+                   "host buffers; includes the copy of the features up and of the [T x %d] result down" % (chunk, P)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="swbd_tri4", choices=sorted(synth.GMM_CONFIGS))
     ap.add_argument("--utts-per-gpu", type=int, default=256)  # 2048 utterances over 8 GPUs
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nnet", action="store_true")
+    ap.add_argument("--no-host-to-host", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # python bench.py --gpus N: one process per GPU under torch.distributed.run, started as a
+        # child before this process touches a GPU; its output and exit code are relayed.
+        port = os.environ.get("MASTER_PORT", "29531")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to print a "
+                 "line whose n_gpus would not be what was asked for" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = "nccl"
@@ -180,6 +244,9 @@ def main():
         if ndev >= world:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if dist.get_world_size() != args.gpus:
+                sys.exit("bench.py: the RCCL process group has %d ranks, --gpus says %d"
+                         % (dist.get_world_size(), args.gpus))
         else:
             # Rehearsal on a box with fewer GPUs than ranks: ranks share devices, which RCCL does
             # not allow, so the summary is reduced over gloo.  Not a scaling measurement.
@@ -245,12 +312,15 @@ def main():
     flop_per_frame = 2.0 * (2 * D + 1) * G
     achieved = flop_per_frame * T / (ms * 1e-3) / 1e12
     if "f16x2" in am.kernel_info():
+        dtype = "f16x2-split operands (3 fp16 MFMA products per fp32-grade product), f32 accumulate"
         peak = BF16_MFMA_PEAK_TFLOPS / F16X2_PRODUCTS
         peak_basis = "fp16 MFMA dense peak 2500 TFLOP/s / 3 fp16 partial products per fp32-grade product"
     elif "bf16x3" in am.kernel_info():
+        dtype = "bf16x3-split operands (6 bf16 MFMA products per fp32-grade product), f32 accumulate"
         peak = BF16_MFMA_PEAK_TFLOPS / BF16X3_PRODUCTS
         peak_basis = "bf16 MFMA dense peak 2500 TFLOP/s / 6 bf16 partial products per fp32-grade product"
     else:
+        dtype = "f32 (fp32 MFMA)"
         peak = FP32_MFMA_PEAK_TFLOPS
         peak_basis = "fp32 MFMA dense peak"
 
@@ -263,7 +333,7 @@ def main():
         traffic = 2.0 * PMC_FETCH_KB * 1e3 + PMC_WRITE_KB * 1e3
         traffic_detail = {"fetch_bytes": 2.0 * PMC_FETCH_KB * 1e3, "write_bytes": PMC_WRITE_KB * 1e3,
                           "algorithmic_bytes": 4.0 * T * P + 4.0 * T * D,
-                          "source": "profiles/r1_i_gmm_diff_pmc_summary.txt"}
+                          "source": "constants from " + PMC_SOURCE + " (rocprofv3 --pmc passes of this workload and kernel; not re-measured by this run)"}
 
     if rank == 0:
         value = tot_frames * args.steps / elapsed
@@ -271,7 +341,7 @@ def main():
             "metric": "acoustic frames/sec", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {
                 "workload": "%s GMM gmm-compute-likes: D=%d, %d pdfs, %d Gaussians; %d utterances/GPU "
                             "(%d frames on rank 0) per step, dense [T x P] log-likelihoods kept in HBM"
@@ -297,8 +367,15 @@ def main():
                                        "both divided like peak",
             },
         }
+        if not args.no_host_to_host:
+            line["host_to_host"] = host_to_host_rate(am, feats, P)
+            line["host_to_host"]["n_gpus"] = 1  # rank 0's frames through rank 0's GPU
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_gmm(model, am.gconsts, D)
+            cb = cpu_baseline_gmm(model, am.gconsts, D)
+            cb["gpu_over_cpu"] = value / cb["value"]
+            if "all_cores" in cb:
+                cb["all_cores"]["gpu_over_cpu"] = value / cb["all_cores"]["value"]
+            line["cpu_baseline"] = cb
         else:
             line["cpu_baseline"] = None
         if not args.no_nnet:
