@@ -41,6 +41,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1643,6 +1644,30 @@ int SetupNoAllocScratch(int device) {
 }
 }  // namespace amlike
 
+namespace amlike {
+// Working memory of the device-pointer entry points for the calls made with one stream: the
+// differenced kernels' control words, and growable buffers for the operand images, the partial
+// sums of split pdfs, the repair list, padded features and per-Gaussian scores.
+struct StreamLane {
+  hipStream_t stream = nullptr;
+  uint64_t last_use = 0;
+  int *d_ctl = nullptr;  // {overflow count, range flag}
+  DeviceBuffer ws_part, ws_pad, ws_expand, ws_expand_safe, ws_fix, ws_gauss, ws_xplanes;
+  void Free() {
+    (void)hipFree(d_ctl);
+    d_ctl = nullptr;
+    ws_part.Free();
+    ws_pad.Free();
+    ws_expand.Free();
+    ws_expand_safe.Free();
+    ws_fix.Free();
+    ws_gauss.Free();
+    ws_xplanes.Free();
+  }
+};
+constexpr size_t kMaxStreamLanes = 8;
+}  // namespace amlike
+
 struct amlike_gmm {
   int32_t num_pdfs = 0, num_gauss = 0, dim = 0;
   int device = 0;
@@ -1655,7 +1680,6 @@ struct amlike_gmm {
   void *d_apack = nullptr;
   void *d_apack_safe = nullptr;  // differenced kernel: the plain bf16x3 image for the fallback
   float *d_bscale = nullptr;     // fp16x2 operands: per k-row feature scale [2][KS * 8]
-  int *d_ctl = nullptr;          // differenced kernel: {overflow count, range flag}
   float *d_gcpack = nullptr;
   float *d_gcpack_safe = nullptr;  // differenced kernels: the plain gconsts for the fallback
   uint32_t *d_endmask = nullptr;
@@ -1673,10 +1697,14 @@ struct amlike_gmm {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
   size_t kev_used = 0;
   void *d_wplanes = nullptr;  // per-Gaussian score GEMM: the model as bf16x3 planes (built on first use)
-  DeviceBuffer ws_xplanes;
   DeviceBuffer ws_raw;  // un-spliced features + speaker transform of amlike_gmm_score_raw
-  DeviceBuffer ws_feats, ws_out, ws_part, ws_pad, ws_expand, ws_expand_safe, ws_fix, ws_gauss;
-  std::mutex mu;
+  DeviceBuffer ws_feats, ws_out, ws_gsel;  // host-pointer entry points (under mu)
+  std::mutex mu;  // the host-pointer entry points, one call at a time
+  // The device-pointer entry points keep one set of working memory per stream they are called
+  // with, so that calls on different streams of one handle may run on the GPU at the same time.
+  std::mutex lane_mu;  // lanes, d_wplanes, info; held while a call enqueues its work
+  std::vector<std::unique_ptr<amlike::StreamLane>> lanes;
+  uint64_t lane_clock = 0;
   std::string info;
 };
 
@@ -2055,10 +2083,6 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
   if (rc == AMLIKE_OK) rc = Upload((void **)&g->d_endmask, endmask.data(), endmask.size() * sizeof(uint32_t));
   if (rc == AMLIKE_OK) rc = Upload((void **)&g->d_segcol, segcol.data(), segcol.size() * sizeof(int32_t));
   if (rc != AMLIKE_OK) return rc;
-  if (vmode == 3) {
-    AMLIKE_HIP(hipMalloc(&g->d_ctl, 2 * sizeof(int)));
-    AMLIKE_HIP(hipMemset(g->d_ctl, 0, 2 * sizeof(int)));
-  }
   if (!splits.empty())
     rc = Upload((void **)&g->d_splits, splits.data(), splits.size() * sizeof(SplitPdf));
   return rc;
@@ -2072,8 +2096,36 @@ struct ScratchArena {
   size_t bytes, used;
 };
 
-static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float *d_out, int ldo,
-                       hipStream_t stream, ScratchArena *arena = nullptr) {
+// The lane of `stream` (g->lane_mu held).  A handle keeps lanes for the kMaxStreamLanes streams
+// used last; one more stream takes over the lane unused for longest, after the device has
+// finished everything (the stream that lane served may no longer exist).
+static int LaneFor(amlike_gmm *g, hipStream_t stream, StreamLane **out) {
+  StreamLane *lane = nullptr;
+  for (auto &l : g->lanes)
+    if (l->stream == stream) lane = l.get();
+  if (!lane) {
+    if (g->lanes.size() < kMaxStreamLanes) {
+      g->lanes.emplace_back(new StreamLane);
+      lane = g->lanes.back().get();
+    } else {
+      for (auto &l : g->lanes)
+        if (!lane || l->last_use < lane->last_use) lane = l.get();
+      AMLIKE_HIP(hipDeviceSynchronize());
+    }
+    lane->stream = stream;
+    if (!lane->d_ctl) {
+      AMLIKE_HIP(hipMalloc(&lane->d_ctl, 2 * sizeof(int)));
+      AMLIKE_HIP(hipMemset(lane->d_ctl, 0, 2 * sizeof(int)));
+    }
+  }
+  lane->last_use = ++g->lane_clock;
+  *out = lane;
+  return AMLIKE_OK;
+}
+
+// `lane`: the working memory of this stream; null with an arena.
+static int LaunchScore(amlike_gmm *g, StreamLane *lane, const float *d_feats, int T, int ld, float *d_out,
+                       int ldo, hipStream_t stream, ScratchArena *arena = nullptr) {
   const Variant &v = *g->variant;
   // bytes from the arena, or from the handle's buffer `ws`
   auto take = [&](DeviceBuffer *ws, size_t bytes, void **out) -> int {
@@ -2135,14 +2187,20 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
   ar.part_m = ar.part_s = nullptr;
   ar.part_ld = 0;
   ar.flag = g->d_flag;
-  ar.ctl = g->d_ctl;
+  ar.ctl = lane ? lane->d_ctl : nullptr;
+  if (arena) {  // the control words come from the arena too
+    void *ctl = nullptr;
+    int rc = take(nullptr, 2 * sizeof(int), &ctl);
+    if (rc != AMLIKE_OK) return rc;
+    ar.ctl = static_cast<int *>(ctl);
+  }
   ar.fix_list = nullptr;
   ar.fix_cap = 0;
   ar.guard = 0;
   if (g->num_partials > 0) {
     const int part_ld = (T + 31) & ~31;
     void *part = nullptr;
-    int rc = take(&g->ws_part, (size_t)2 * g->num_partials * part_ld * sizeof(float), &part);
+    int rc = take(lane ? &lane->ws_part : nullptr, (size_t)2 * g->num_partials * part_ld * sizeof(float), &part);
     if (rc != AMLIKE_OK) return rc;
     ar.part_m = static_cast<float *>(part);
     ar.part_s = ar.part_m + (size_t)g->num_partials * part_ld;
@@ -2164,7 +2222,7 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
       a.bx = static_cast<const uint4 *>(image);
       const int threads = num_ftiles * KS * 64;
       hipLaunchKernelGGL(expand, dim3((threads + 255) / 256), dim3(256), 0, stream, d_feats, T, ld,
-                         g->dim, static_cast<uint4 *>(image), num_ftiles, g->d_bscale, g->d_ctl,
+                         g->dim, static_cast<uint4 *>(image), num_ftiles, g->d_bscale, ar.ctl,
                          a.fix_cap, guard == 2 ? 2 : 0);
       AMLIKE_HIP(hipGetLastError());
       smem = 2 * FramesTilesPerBarrier(v.W, KS, parts) * tile_bytes + (size_t)v.W * v.NT * 32 * 4 +
@@ -2184,7 +2242,7 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
     if (g->num_splits > 0 && v.mode < 100) {
       hipLaunchKernelGGL(gmm_merge_parts_kernel, dim3((T + 255) / 256, g->num_splits), dim3(256), 0,
                          stream, g->d_splits, g->num_splits, a.part_m, a.part_s, a.part_ld, T, d_out,
-                         ldo, g->d_flag, g->d_ctl, a.fix_list, a.fix_cap, guard);
+                         ldo, g->d_flag, ar.ctl, a.fix_list, a.fix_cap, guard);
       AMLIKE_HIP(hipGetLastError());
     }
     return AMLIKE_OK;
@@ -2196,24 +2254,25 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
     const size_t cap = std::max<size_t>(4096, std::min<size_t>(arena ? (size_t)1 << 14 : (size_t)1 << 21,
                                                               (size_t)T * g->num_pdfs / 256));
     void *fix = nullptr;
-    int rc = take(&g->ws_fix, cap * sizeof(int2), &fix);
+    int rc = take(lane ? &lane->ws_fix : nullptr, cap * sizeof(int2), &fix);
     if (rc != AMLIKE_OK) return rc;
     ar.fix_list = static_cast<int2 *>(fix);
     ar.fix_cap = (int)cap;
-    AMLIKE_HIP(hipMemsetAsync(g->d_ctl, 0, 2 * sizeof(int), stream));
-    rc = pass(v.kernel, v.expand, v.prec ? 2 : 3, g->d_apack, g->d_gcpack, &g->ws_expand, 1);
+    AMLIKE_HIP(hipMemsetAsync(ar.ctl, 0, 2 * sizeof(int), stream));
+    rc = pass(v.kernel, v.expand, v.prec ? 2 : 3, g->d_apack, g->d_gcpack, lane ? &lane->ws_expand : nullptr, 1);
     if (rc != AMLIKE_OK) return rc;
     if (v.mode >= 300) return AMLIKE_OK;  // timing experiments: the main kernel alone
-    hipLaunchKernelGGL(gmm_fix_kernel, dim3(1024), dim3(256), 0, stream, g->d_ctl, ar.fix_list, ar.fix_cap,
+    hipLaunchKernelGGL(gmm_fix_kernel, dim3(1024), dim3(256), 0, stream, ar.ctl, ar.fix_list, ar.fix_cap,
                        g->d_gconsts, g->d_miv, g->d_iv, g->d_offsets, g->dim, d_feats, ld, d_out, ldo,
                        g->d_flag);
     AMLIKE_HIP(hipGetLastError());
     rc = pass(v.safe_kernel, v.safe_expand, 3, g->d_apack_safe ? g->d_apack_safe : g->d_apack,
               g->d_gcpack_safe ? g->d_gcpack_safe : g->d_gcpack,
-              v.prec ? &g->ws_expand_safe : &g->ws_expand, 2);
+              !lane ? nullptr : v.prec ? &lane->ws_expand_safe : &lane->ws_expand, 2);
     if (rc != AMLIKE_OK) return rc;
   } else {
-    int rc = pass(v.kernel, v.mode >= 1 ? v.expand : nullptr, 3, g->d_apack, g->d_gcpack, &g->ws_expand, 0);
+    int rc = pass(v.kernel, v.mode >= 1 ? v.expand : nullptr, 3, g->d_apack, g->d_gcpack,
+                  lane ? &lane->ws_expand : nullptr, 0);
     if (rc != AMLIKE_OK) return rc;
   }
   if (arena) return AMLIKE_OK;  // (the description below is a heap-allocated string)
@@ -2225,7 +2284,7 @@ static int LaunchScore(amlike_gmm *g, const float *d_feats, int T, int ld, float
 }
 
 // Makes the features conform (16-byte aligned rows); returns the pointer/stride to use.
-static int ConformFeats(amlike_gmm *g, const float *d_feats, int T, int ld, hipStream_t stream,
+static int ConformFeats(amlike_gmm *g, StreamLane *lane, const float *d_feats, int T, int ld, hipStream_t stream,
                         const float **use, int *use_ld) {
   const bool ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_feats) & 15) == 0) &&
                   ld >= ((g->dim + 3) & ~3);
@@ -2235,14 +2294,14 @@ static int ConformFeats(amlike_gmm *g, const float *d_feats, int T, int ld, hipS
     return AMLIKE_OK;
   }
   const int ldp = (g->dim + 3) & ~3;
-  int rc = g->ws_pad.Reserve((size_t)T * ldp * sizeof(float));
+  int rc = lane->ws_pad.Reserve((size_t)T * ldp * sizeof(float));
   if (rc != AMLIKE_OK) return rc;
   const size_t n = (size_t)T * ldp;
   const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(gmm_pad_feats_kernel, dim3(blocks), dim3(256), 0, stream, d_feats, T, ld,
-                     g->dim, static_cast<float *>(g->ws_pad.ptr), ldp);
+                     g->dim, static_cast<float *>(lane->ws_pad.ptr), ldp);
   AMLIKE_HIP(hipGetLastError());
-  *use = static_cast<const float *>(g->ws_pad.ptr);
+  *use = static_cast<const float *>(lane->ws_pad.ptr);
   *use_ld = ldp;
   return AMLIKE_OK;
 }
@@ -2265,6 +2324,51 @@ static int CheckScoreArgs(const amlike_gmm *g, int T, int ld, int feat_dim, int 
 }
 
 }  // namespace amlike
+
+// Per-Gaussian scores of pdfs [pdf_begin, pdf_end) for device features (arguments checked by the
+// caller, g->lane_mu held).
+static int GaussLoglikesDevLocked(amlike_gmm *g, amlike::StreamLane *lane, int pdf_begin, int pdf_end,
+                                  const float *d_feats, int T, int ld, float *d_out, int ldo,
+                                  hipStream_t st) {
+  using namespace amlike;
+  const int g0 = g->pdf_offsets[pdf_begin], g1 = g->pdf_offsets[pdf_end];
+  const size_t valu_smem = (size_t)3 * 64 * (g->dim + 1) * sizeof(float);
+  if ((T >= 64 && g1 - g0 >= 64 && !getenv("AMLIKE_GMM_GAUSS_VALU")) || valu_smem > 64 * 1024) {
+    // A [T x 2D] . [2D x M] product with the gconsts as bias: the bf16x3 matrix-instruction
+    // GEMM of the nnet2 path, on plane images of the features (per call) and of the model
+    // (once per handle).
+    const int Kp = (2 * g->dim + 15) & ~15, kp8 = Kp >> 3;
+    const size_t G = (size_t)g->num_gauss;
+    if (!g->d_wplanes) {
+      AMLIKE_HIP(hipMalloc(&g->d_wplanes, 3 * G * kp8 * sizeof(uint4)));
+      const int blocks = (int)std::min<size_t>((G * kp8 + 255) / 256, 16384);
+      hipLaunchKernelGGL(gmm_gemm_planes_kernel<true>, dim3(blocks), dim3(256), 0, st, g->d_miv, g->d_iv,
+                         g->dim, g->dim, g->num_gauss, static_cast<uint4 *>(g->d_wplanes), G * kp8, kp8);
+      AMLIKE_HIP(hipGetLastError());
+      AMLIKE_HIP(hipStreamSynchronize(st));  // calls on other streams read it from now on
+    }
+    int rc = lane->ws_xplanes.Reserve((size_t)3 * T * kp8 * sizeof(uint4));
+    if (rc != AMLIKE_OK) return rc;
+    const int blocks = (int)std::min<size_t>(((size_t)T * kp8 + 255) / 256, 16384);
+    hipLaunchKernelGGL(gmm_gemm_planes_kernel<false>, dim3(blocks), dim3(256), 0, st, d_feats, d_feats, ld,
+                       g->dim, T, static_cast<uint4 *>(lane->ws_xplanes.ptr), (size_t)T * kp8, kp8);
+    AMLIKE_HIP(hipGetLastError());
+    return LaunchPlaneGemmBf16x3(lane->ws_xplanes.ptr, (size_t)T * kp8,
+                                 static_cast<const uint4 *>(g->d_wplanes) + g0, G * kp8, G, Kp,
+                                 g->d_gconsts + g0, d_out, ldo, T, g1 - g0, st);
+  }
+  const size_t smem = (size_t)3 * 64 * (g->dim + 1) * sizeof(float);
+  if (smem > 64 * 1024) {
+    SetError("amlike_gmm_gauss_loglikes: dim %d too large", g->dim);
+    return AMLIKE_EDIM;
+  }
+  dim3 grid((g1 - g0 + 63) / 64, (T + 63) / 64);
+  hipLaunchKernelGGL(gmm_gauss_loglikes_kernel, grid, dim3(256), smem,
+                     st, g->d_gconsts, g->d_miv, g->d_iv, g0, g1,
+                     g->dim, d_feats, T, ld, d_out, ldo);
+  AMLIKE_HIP(hipGetLastError());
+  return AMLIKE_OK;
+}
 
 extern "C" {
 
@@ -2342,9 +2446,7 @@ int amlike_gmm_destroy(amlike_gmm_t *g) {
   (void)hipFree(g->d_apack_safe);
   (void)hipFree(g->d_bscale);
   (void)hipFree(g->d_gcpack_safe);
-  (void)hipFree(g->d_ctl);
-  g->ws_expand_safe.Free();
-  g->ws_fix.Free();
+  for (auto &l : g->lanes) l->Free();
   (void)hipFree(g->d_gcpack);
   (void)hipFree(g->d_endmask);
   (void)hipFree(g->d_segcol);
@@ -2354,15 +2456,11 @@ int amlike_gmm_destroy(amlike_gmm_t *g) {
   (void)hipFree(g->d_iv);
   (void)hipFree(g->d_flag);
   (void)hipFree(g->d_offsets);
-  g->ws_gauss.Free();
   g->ws_feats.Free();
+  g->ws_gsel.Free();
   g->ws_raw.Free();
-  g->ws_xplanes.Free();
   (void)hipFree(g->d_wplanes);
   g->ws_out.Free();
-  g->ws_part.Free();
-  g->ws_pad.Free();
-  g->ws_expand.Free();
   for (AsyncSlot &s : g->slots) s.Release();
   for (auto &e : g->kev) {
     (void)hipEventDestroy(e.first);
@@ -2386,6 +2484,10 @@ int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32
   int rc = CheckScoreArgs(g, T, ld, feat_dim, ldo, d_feats, d_out);
   if (rc != AMLIKE_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lane_lock(g->lane_mu);
+  StreamLane *lane = nullptr;
+  rc = LaneFor(g, st, &lane);
+  if (rc != AMLIKE_OK) return rc;
   if (log_sum_exp_prune > 0.0f || !g->variant) {
     // Pruning needs each pdf's maximum before its sum, so this mode goes through the
     // per-Gaussian scores, in frame chunks that bound the scratch matrix.
@@ -2394,18 +2496,22 @@ int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32
     size_t budget = (size_t)1 << 28;  // floats
     if (const char *e = getenv("AMLIKE_GMM_PRUNE_SCRATCH_MB")) budget = (size_t)std::max(1, atoi(e)) << 18;
     const int chunk = std::max(64, (int)std::min<size_t>((size_t)T, budget / (size_t)G));
-    rc = g->ws_gauss.Reserve((size_t)std::min(chunk, T) * G * sizeof(float));
+    rc = lane->ws_gauss.Reserve((size_t)std::min(chunk, T) * G * sizeof(float));
     if (rc != AMLIKE_OK) return rc;
-    float *scores = static_cast<float *>(g->ws_gauss.ptr);
+    float *scores = static_cast<float *>(lane->ws_gauss.ptr);
+    // the log-sum-exp kernel takes a block per frame in grid.y, which holds 65535
+    const int launch_rows = 32768;
     for (int t0 = 0; t0 < T; t0 += chunk) {
       const int tn = std::min(chunk, T - t0);
-      rc = amlike_gmm_gauss_loglikes_dev(g, 0, g->num_pdfs, d_feats + (size_t)t0 * ld, tn, ld,
-                                         feat_dim, scores, G, stream);
+      rc = GaussLoglikesDevLocked(g, lane, 0, g->num_pdfs, d_feats + (size_t)t0 * ld, tn, ld, scores, G, st);
       if (rc != AMLIKE_OK) return rc;
-      hipLaunchKernelGGL(gmm_pruned_lse_kernel, dim3((g->num_pdfs + 255) / 256, tn), dim3(256), 0, st,
-                         scores, G, g->d_offsets, g->num_pdfs, tn, log_sum_exp_prune,
-                         d_out + (size_t)t0 * ldo, ldo, g->d_flag);
-      AMLIKE_HIP(hipGetLastError());
+      for (int r0 = 0; r0 < tn; r0 += launch_rows) {
+        const int rn = std::min(launch_rows, tn - r0);
+        hipLaunchKernelGGL(gmm_pruned_lse_kernel, dim3((g->num_pdfs + 255) / 256, rn), dim3(256), 0, st,
+                           scores + (size_t)r0 * G, G, g->d_offsets, g->num_pdfs, rn, log_sum_exp_prune,
+                           d_out + (size_t)(t0 + r0) * ldo, ldo, g->d_flag);
+        AMLIKE_HIP(hipGetLastError());
+      }
     }
     if (g->variant) g->info = "pruned log-sum-exp over per-Gaussian scores";
     return AMLIKE_OK;
@@ -2413,10 +2519,10 @@ int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32
   const float *use = d_feats;
   int use_ld = ld;
   if (g->variant->mode == 0) {  // the fp32 kernel reads rows as float4
-    rc = ConformFeats(g, d_feats, T, ld, st, &use, &use_ld);
+    rc = ConformFeats(g, lane, d_feats, T, ld, st, &use, &use_ld);
     if (rc != AMLIKE_OK) return rc;
   }
-  return LaunchScore(g, use, T, use_ld, d_out, ldo, st);
+  return LaunchScore(g, lane, use, T, use_ld, d_out, ldo, st);
 }
 
 int amlike_gmm_score_dev_noalloc(amlike_gmm_t *g, const float *d_feats, int32_t T, int32_t ld,
@@ -2435,7 +2541,8 @@ int amlike_gmm_score_dev_noalloc(amlike_gmm_t *g, const float *d_feats, int32_t 
     return AMLIKE_EINVAL;
   }
   ScratchArena arena{base, kNoAllocScratchBytes, 0};
-  return LaunchScore(g, d_feats, T, ld, d_out, ldo, static_cast<hipStream_t>(stream), &arena);
+  std::lock_guard<std::mutex> lane_lock(g->lane_mu);
+  return LaunchScore(g, nullptr, d_feats, T, ld, d_out, ldo, static_cast<hipStream_t>(stream), &arena);
 }
 
 size_t amlike_gmm_noalloc_scratch_bytes(void) { return kNoAllocScratchBytes; }
@@ -2642,41 +2749,11 @@ int amlike_gmm_gauss_loglikes_dev(amlike_gmm_t *g, int32_t pdf_begin, int32_t pd
     return AMLIKE_EINVAL;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t valu_smem = (size_t)3 * 64 * (g->dim + 1) * sizeof(float);
-  if ((T >= 64 && g1 - g0 >= 64 && !getenv("AMLIKE_GMM_GAUSS_VALU")) || valu_smem > 64 * 1024) {
-    // A [T x 2D] . [2D x M] product with the gconsts as bias: the bf16x3 matrix-instruction
-    // GEMM of the nnet2 path, on plane images of the features (per call) and of the model
-    // (once per handle).
-    const int Kp = (2 * g->dim + 15) & ~15, kp8 = Kp >> 3;
-    const size_t G = (size_t)g->num_gauss;
-    if (!g->d_wplanes) {
-      AMLIKE_HIP(hipMalloc(&g->d_wplanes, 3 * G * kp8 * sizeof(uint4)));
-      const int blocks = (int)std::min<size_t>((G * kp8 + 255) / 256, 16384);
-      hipLaunchKernelGGL(gmm_gemm_planes_kernel<true>, dim3(blocks), dim3(256), 0, st, g->d_miv, g->d_iv,
-                         g->dim, g->dim, g->num_gauss, static_cast<uint4 *>(g->d_wplanes), G * kp8, kp8);
-      AMLIKE_HIP(hipGetLastError());
-    }
-    int rc = g->ws_xplanes.Reserve((size_t)3 * T * kp8 * sizeof(uint4));
-    if (rc != AMLIKE_OK) return rc;
-    const int blocks = (int)std::min<size_t>(((size_t)T * kp8 + 255) / 256, 16384);
-    hipLaunchKernelGGL(gmm_gemm_planes_kernel<false>, dim3(blocks), dim3(256), 0, st, d_feats, d_feats, ld,
-                       g->dim, T, static_cast<uint4 *>(g->ws_xplanes.ptr), (size_t)T * kp8, kp8);
-    AMLIKE_HIP(hipGetLastError());
-    return LaunchPlaneGemmBf16x3(g->ws_xplanes.ptr, (size_t)T * kp8,
-                                 static_cast<const uint4 *>(g->d_wplanes) + g0, G * kp8, G, Kp,
-                                 g->d_gconsts + g0, d_out, ldo, T, g1 - g0, st);
-  }
-  const size_t smem = (size_t)3 * 64 * (g->dim + 1) * sizeof(float);
-  if (smem > 64 * 1024) {
-    SetError("amlike_gmm_gauss_loglikes: dim %d too large", g->dim);
-    return AMLIKE_EDIM;
-  }
-  dim3 grid((g1 - g0 + 63) / 64, (T + 63) / 64);
-  hipLaunchKernelGGL(gmm_gauss_loglikes_kernel, grid, dim3(256), smem,
-                     static_cast<hipStream_t>(stream), g->d_gconsts, g->d_miv, g->d_iv, g0, g1,
-                     g->dim, d_feats, T, ld, d_out, ldo);
-  AMLIKE_HIP(hipGetLastError());
-  return AMLIKE_OK;
+  std::lock_guard<std::mutex> lane_lock(g->lane_mu);
+  StreamLane *lane = nullptr;
+  int rc = LaneFor(g, st, &lane);
+  if (rc != AMLIKE_OK) return rc;
+  return GaussLoglikesDevLocked(g, lane, pdf_begin, pdf_end, d_feats, T, ld, d_out, ldo, st);
 }
 
 int amlike_gmm_gauss_loglikes(amlike_gmm_t *g, int32_t pdf_begin, int32_t pdf_end,
@@ -2750,12 +2827,12 @@ int amlike_gmm_gselect(amlike_gmm_t *g, int32_t pdf, const float *feats, int32_t
   for (int t0 = 0; t0 < T; t0 += max_t) {
     const int tn = std::min(max_t, T - t0);
     int rc = g->ws_feats.Reserve((size_t)tn * dld * sizeof(float));
-    if (rc == AMLIKE_OK) rc = g->ws_gauss.Reserve((size_t)tn * M * sizeof(float));
+    if (rc == AMLIKE_OK) rc = g->ws_gsel.Reserve((size_t)tn * M * sizeof(float));
     if (rc == AMLIKE_OK)
       rc = g->ws_out.Reserve((size_t)tn * num_gselect * sizeof(int32_t) + (size_t)tn * sizeof(float));
     if (rc != AMLIKE_OK) return rc;
     float *df = static_cast<float *>(g->ws_feats.ptr);
-    float *dscore = static_cast<float *>(g->ws_gauss.ptr);
+    float *dscore = static_cast<float *>(g->ws_gsel.ptr);
     int32_t *didx = static_cast<int32_t *>(g->ws_out.ptr);
     float *dll = reinterpret_cast<float *>(didx + (size_t)tn * num_gselect);
     if (feats_1d)
@@ -2784,7 +2861,7 @@ int amlike_gmm_gselect(amlike_gmm_t *g, int32_t pdf, const float *feats, int32_t
 int amlike_gmm_profile_kernel(amlike_gmm_t *g, int32_t enable) {
   if (int brc = BindThread()) return brc;
   if (!g) return AMLIKE_EINVAL;
-  std::lock_guard<std::mutex> lock(g->mu);
+  std::lock_guard<std::mutex> lock(g->lane_mu);
   if (enable && g->kev.empty()) {
     g->kev.resize(256);
     for (auto &e : g->kev) {
@@ -2801,7 +2878,7 @@ int amlike_gmm_profile_kernel(amlike_gmm_t *g, int32_t enable) {
 int amlike_gmm_kernel_time(amlike_gmm_t *g, float *mean_ms, int32_t *launches) {
   if (int brc = BindThread()) return brc;
   if (!g || !mean_ms) return AMLIKE_EINVAL;
-  std::lock_guard<std::mutex> lock(g->mu);
+  std::lock_guard<std::mutex> lock(g->lane_mu);
   double sum = 0.0;
   for (size_t i = 0; i < g->kev_used; ++i) {
     AMLIKE_HIP(hipEventSynchronize(g->kev[i].second));

@@ -32,6 +32,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "amlike_common.h"
@@ -39,6 +40,7 @@
 namespace amlike {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 
 static inline int RoundUp(int x, int m) { return (x + m - 1) / m * m; }
 // Results larger than this are streamed past the caches (non-temporal stores).
@@ -1031,6 +1033,293 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Output layer and softmax in one kernel (the last AffineComponent of a net followed by its
+// SoftmaxComponent, nnet2/nnet-component.cc:1123-1131 and :905-918, with the floor / log /
+// minus log-prior / scale of nnet2bin/nnet-am-compute.cc:93-96 and nnet2/decodable-am-nnet.h:57-73):
+// the [rows x N] matrix is written once and never read back.  Two sweeps over the N units:
+// the first forms the product tile by tile and keeps only each row's running (max, sum of
+// exponentials); the second forms the product again and writes the finished value.  The second
+// product costs far less than reading and re-writing the matrix (N = 8600: 34 KB per row).
+//
+// A wave owns FT tiles of 32 rows (frames) for a whole job and keeps their operand fragments
+// of X in registers (frames are the matrix instruction's columns, one per lane); the units are
+// its rows, so a lane holds 16 units of a 32-unit tile for its frame.  The W tiles stream
+// through LDS (a ring of kOutRing tiles, global_load ... lds), shared by the block's 4 waves;
+// one wave per SIMD, 512 registers.  The vector work of tile t - 1 (softmax statistics or
+// output stores) is interleaved with the matrix instructions of tile t.
+// A job = up to 256 consecutive rows (64 per wave, FT = 2) or up to 128 (32 per wave, FT = 1);
+// the host cuts the rows into jobs so that the last round of jobs is short on every CU
+// instead of long on a few.
+constexpr int kOutRing = 3;
+// An empty volatile asm that takes and returns `x` in a vector register: instructions that
+// produce x stay before it and instructions that use x stay after it in program order.
+__device__ __forceinline__ void pin_order(float &x) {
+#if __HIP_DEVICE_COMPILE__  // the host pass cannot parse the vector-register constraint
+  asm volatile("" : "+v"(x));
+#endif
+}
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f) {  // f(integral_constant<int, I>) for I = 0 .. N-1
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<N, I + 1>(f);
+  }
+}
+struct OutJobs {
+  int nbig;    // jobs of 256 rows, first
+  int small;   // rows per remaining job (multiple of 32, <= 128 for FT = 1)
+};
+
+template <int KS, int PREC>
+__global__ void __launch_bounds__(256, 1)
+    nnet_out_softmax_kernel(const uint4 *__restrict__ Xp, size_t xplane, const uint4 *__restrict__ Wp,
+                            size_t wplane, const float *__restrict__ bias_pad,
+                            const float *__restrict__ logprior_pad, float *__restrict__ Y, int ldy, int M,
+                            int N, int post, float scale, OutJobs jobs) {
+  constexpr int NPL = PREC ? 2 : 3, NPROD = PREC ? 3 : 6;
+  constexpr int kTileU4 = NPL * 2 * KS * 32;  // uint4 per staged W tile: [plane][octet][32 units]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_o[];
+  uint4 *s_w = reinterpret_cast<uint4 *>(smem_o);
+  // beside the W ring, a ring of 4 x (32 biases, 32 log priors): a tile's log priors are still
+  // read one step after the tile itself (by the stores), so they outlive its W slot by a step
+  float *s_bp = reinterpret_cast<float *>(s_w + kOutRing * kTileU4);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  int row0, nrows;
+  if ((int)blockIdx.x < jobs.nbig) {
+    row0 = blockIdx.x * 256;
+    nrows = 256;
+  } else {
+    row0 = jobs.nbig * 256 + ((int)blockIdx.x - jobs.nbig) * jobs.small;
+    nrows = min(jobs.small, M - row0);
+  }
+  if (nrows <= 0) return;
+  const int ntile = (N + 31) >> 5;
+  const int total = 2 * ntile;  // W tiles to stream: both sweeps
+
+  auto run = [&](auto ft_tag) __attribute__((always_inline)) {
+    constexpr int FT = decltype(ft_tag)::value;
+    // W tile `seq % ntile` travels global -> registers (fetch, at the start of a step) -> LDS ring
+    // slot seq % kOutRing (commit, at the end of the step): pieces of 1 KiB (64 lanes x 16 bytes:
+    // two octets of one plane for 32 units), dealt round-robin to the 4 waves.
+    constexpr int kPieces = NPL * KS, kMine = (kPieces + 3) / 4;
+    bf16x8_t wreg[kMine];
+    float breg = 0.0f;  // wave 3: lanes 0-31 a bias, lanes 32-63 a log prior of the tile
+    auto fetch = [&](int seq) __attribute__((always_inline)) {
+      const int n0 = (seq % ntile) << 5;
+#pragma unroll
+      for (int i = 0; i < kMine; ++i) {
+        const int piece = min(w + 4 * i, kPieces - 1);
+        const int q = piece / KS, op = piece - q * KS;  // plane, octet pair
+        wreg[i] = __builtin_bit_cast(bf16x8_t, Wp[(size_t)q * wplane + (size_t)(2 * op + h) * N + min(n0 + li, N - 1)]);
+      }
+      if (w == 3) breg = h ? logprior_pad[n0 + li] : bias_pad[n0 + li];
+    };
+    auto commit = [&](int seq) __attribute__((always_inline)) {
+      uint4 *dst = s_w + (seq % kOutRing) * kTileU4;
+#pragma unroll
+      for (int i = 0; i < kMine; ++i)
+        if (w + 4 * i < kPieces) dst[(w + 4 * i) * 64 + lane] = __builtin_bit_cast(uint4, wreg[i]);
+      if (w == 3) s_bp[(seq & 3) * 64 + lane] = breg;
+    };
+    const int wrow0 = row0 + w * 32 * FT;  // this wave's first row
+    // X fragments, resident: [frame tile][k-step][plane]
+    bf16x8_t xf[FT][KS][NPL];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      const size_t r = (size_t)min(wrow0 + 32 * f + li, M - 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int q = 0; q < NPL; ++q)
+          xf[f][ks][q] = __builtin_bit_cast(bf16x8_t, Xp[(size_t)q * xplane + (size_t)(2 * ks + h) * M + r]);
+    }
+    float mx[FT], sm[FT], logz[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      mx[f] = -INFINITY;
+      sm[f] = 0.0f;
+      logz[f] = 0.0f;
+    }
+    // the first two tiles of the stream
+    fetch(0);
+    commit(0);
+    fetch(1);
+    commit(1);
+
+    // sweep 1, the vector work on one finished tile: running (max, sum) of its 16 units per
+    // lane.  part 0: the tile's maximum and the rescaling of the sum; parts 1..4: four units each
+    auto stats_part = [&](const f32x16 (&acc)[FT], int part) __attribute__((always_inline)) {
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        if (part == 0) {
+          float m = acc[f][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[f][r]);
+          const float mn = fmaxf(mx[f], m);
+          sm[f] *= __expf(mx[f] - mn);  // exp(-inf) = 0 on the first tile, where sm is 0 too
+          mx[f] = mn;
+        } else {
+#pragma unroll
+          for (int r = 4 * (part - 1); r < 4 * part; ++r) sm[f] += __expf(acc[f][r] - mx[f]);
+        }
+        pin_order(sm[f]);  // the part stays in the k-step it was written in
+        pin_order(mx[f]);
+      }
+    };
+    // sweep 2, the vector work on one finished tile: units 8 part + 4 h .. + 3 of tile n0
+    auto store_part = [&](const f32x16 (&acc)[FT], int n0, int old_seq, int part) __attribute__((always_inline)) {
+      if (part >= 4) return;
+      const int c = n0 + 8 * part + 4 * h;
+      if (c >= N) return;
+      float4 lp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (post & kPostPrior)
+        lp = *reinterpret_cast<const float4 *>(s_bp + (old_seq & 3) * 64 + 32 + 8 * part + 4 * h);
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        const int row = wrow0 + 32 * f + li;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float lsm = acc[f][4 * part + i] - logz[f];  // log softmax
+          if (post & kPostFloorLog) v[i] = fmaxf(lsm, -46.051701859880914f);  // log(1e-20)
+          else v[i] = floor_1e20(__expf(lsm));
+        }
+        if (post & kPostPrior) {
+          v[0] = (v[0] - lp.x) * scale;
+          v[1] = (v[1] - lp.y) * scale;
+          v[2] = (v[2] - lp.z) * scale;
+          v[3] = (v[3] - lp.w) * scale;
+        }
+        if (row < row0 + nrows)
+          *reinterpret_cast<float4 *>(Y + (size_t)row * ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    };
+
+    // Fragments of W for the matrix instructions, read from LDS kAhead k-steps before their use;
+    // the stream of k-steps runs on across tile boundaries (tile seq + 1 sits in LDS while tile
+    // seq is multiplied), so the read latency is exposed once per job, not once per tile.
+    constexpr int kAhead = 2;
+    static_assert(KS % 3 == 1, "the register slots below assume KS = 3 n + 1");
+    // k-step j of any tile uses register slot j % 3, the last k-step slot 3: any kAhead + 1
+    // consecutive k-steps of the stream, tile boundaries included, sit in distinct slots
+    bf16x8_t wf[4][NPL];
+    auto load_frag = [&](int seq, auto ks_tag) __attribute__((always_inline)) {  // k-step ks of tile seq
+      constexpr int ks = decltype(ks_tag)::value, slot = ks == KS - 1 ? 3 : ks % 3;
+      const uint4 *wt = s_w + (seq % kOutRing) * kTileU4;
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+        wf[slot][q] = __builtin_bit_cast(bf16x8_t, wt[(q * 2 * KS + 2 * ks + h) * 32 + li]);
+    };
+    float4 bnext[4];  // the biases of the lane's 16 units of the next tile
+    auto load_bias = [&](int seq) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+        bnext[q4] = *reinterpret_cast<const float4 *>(s_bp + (seq & 3) * 64 + 8 * q4 + 4 * h);
+    };
+    // One step of the stream: the matrix instructions of W tile seq into acc_new (initialised
+    // with the bias), with the vector work of the previous tile (acc_old; kind 0: none, 1: sweep-1
+    // statistics, 2: sweep-2 stores of tile old_n0) spread between them.  On entry the fragments
+    // of k-steps 0 .. kAhead-1 of tile seq and its biases have been requested.
+    auto step = [&](int seq, f32x16 (&acc_new)[FT], const f32x16 (&acc_old)[FT], auto kind_tag,
+                    int old_n0) __attribute__((always_inline)) {
+      constexpr int kKind = decltype(kind_tag)::value;
+      const bool more = seq + 2 < total;
+      if (more) fetch(seq + 2);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+          acc_new[f][4 * q4 + 0] = bnext[q4].x;
+          acc_new[f][4 * q4 + 1] = bnext[q4].y;
+          acc_new[f][4 * q4 + 2] = bnext[q4].z;
+          acc_new[f][4 * q4 + 3] = bnext[q4].w;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<KS>([&](auto ks_tag) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_tag)::value;
+        // the fragments kAhead k-steps on: of this tile, or of the next one (already in LDS)
+        if constexpr (ks + kAhead < KS) {
+          load_frag(seq, std::integral_constant<int, (ks + kAhead) % KS>());
+        } else {
+          if (seq + 1 < total) load_frag(seq + 1, std::integral_constant<int, (ks + kAhead) % KS>());
+          if (ks == KS - 1 && seq + 1 < total) load_bias(seq + 1);
+        }
+        constexpr int slot = ks == KS - 1 ? 3 : ks % 3;
+#pragma unroll
+        for (int which = 0; which < NPROD; ++which) {
+          int pa, pb;
+          product_parts<PREC>(which, pa, pb);
+#pragma unroll
+          for (int f = 0; f < FT; ++f)
+            acc_new[f] = mfma16<PREC>(wf[slot][pa], xf[f][ks][pb], acc_new[f]);
+        }
+        if (kKind != 0) {
+          constexpr int kParts = 5;
+#pragma unroll
+          for (int part = (ks * kParts) / KS; part < ((ks + 1) * kParts) / KS; ++part) {
+            if (kKind == 1) stats_part(acc_old, part);
+            else store_part(acc_old, old_n0, seq - 1, part);
+          }
+        }
+        // nothing moves across a k-step: the LDS reads stay kAhead k-steps ahead of their use
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if (more) commit(seq + 2);
+      // every wave has committed its pieces of tile seq + 2 and has finished reading tile seq
+      __syncthreads();
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    f32x16 acc_a[FT], acc_b[FT];
+    __syncthreads();  // tiles 0 and 1 are in LDS
+    load_bias(0);
+    static_for<kAhead>([&](auto j) __attribute__((always_inline)) { load_frag(0, j); });
+    // sweep 1
+    step(0, acc_a, acc_b, K0(), 0);
+    bool in_a = true;  // which set holds the tile finished last
+    for (int t = 1; t < ntile; t += 2) {
+      step(t, acc_b, acc_a, K1(), 0);
+      in_a = false;
+      if (t + 1 < ntile) {
+        step(t + 1, acc_a, acc_b, K1(), 0);
+        in_a = true;
+      }
+    }
+#pragma unroll
+    for (int part = 0; part < 5; ++part) {
+      if (in_a) stats_part(acc_a, part);
+      else stats_part(acc_b, part);
+    }
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {  // the two half-waves hold different units of the same rows
+      const float om = __shfl_xor(mx[f], 32), os = __shfl_xor(sm[f], 32);
+      const float mn = fmaxf(mx[f], om);
+      logz[f] = mn + __logf(sm[f] * __expf(mx[f] - mn) + os * __expf(om - mn));
+    }
+    // sweep 2
+    step(ntile, acc_a, acc_b, K0(), 0);
+    in_a = true;
+    for (int t = 1; t < ntile; t += 2) {
+      step(ntile + t, acc_b, acc_a, K2(), (t - 1) << 5);
+      in_a = false;
+      if (t + 1 < ntile) {
+        step(ntile + t + 1, acc_a, acc_b, K2(), t << 5);
+        in_a = true;
+      }
+    }
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+      if (in_a) store_part(acc_a, (ntile - 1) << 5, total - 1, part);
+      else store_part(acc_b, (ntile - 1) << 5, total - 1, part);
+    }
+  };
+  if (nrows <= 128) run(std::integral_constant<int, 1>());
+  else run(std::integral_constant<int, 2>());
+}
+
 // Softmax for rows wider than the register form holds: three passes over the row.
 __global__ void __launch_bounds__(256)
     nnet_softmax_wide_kernel(const float *__restrict__ in, int ld_in, int dim, int rows, int post,
@@ -1258,6 +1547,61 @@ static std::vector<uint16_t> BuildPnormWeights(const std::vector<float> &w, int 
   }
   (void)kp8;
   return out;
+}
+
+// Does the fused output-layer + softmax kernel take stage si (an AffineComponent) and the
+// SoftmaxComponent behind it?  It covers the nets' usual end: affine, softmax, nothing after;
+// operands on fixed fp16x2 or bf16x3 planes; k padded to 208 (inputs of 193..208 dimensions)
+// or 304; rows of the result 16-byte aligned.
+static bool FusedOutputApplies(const amlike_nnet *n, size_t si, const float *d_out, int ldo, int post) {
+  (void)post;
+  if (getenv("AMLIKE_NNET_NO_FUSED_OUT") || n->gemm_f32 || n->gemm_inline_split) return false;
+  if (si + 2 != n->stages.size()) return false;
+  const Stage &s = n->stages[si], &sm = n->stages[si + 1];
+  if (s.kind != AMLIKE_AFFINE || s.fuse_gs || sm.kind != AMLIKE_SOFTMAX || s.f16 == 2) return false;
+  if (s.Kp != 208 && !(s.Kp == 304 && s.f16)) return false;  // (bf16x3 fragments at k = 304 do not fit the registers)
+  if ((s.out_dim & 7) || (ldo & 3) || (reinterpret_cast<uintptr_t>(d_out) & 15)) return false;
+  if (n->num_priors != 0 && n->num_priors != s.out_dim) return false;
+  return true;
+}
+
+static int LaunchOutSoftmax(const Stage &s, const uint4 *xp, size_t xplane, const float *log_priors,
+                            float *y, int ldy, int rows, int post, float scale, hipStream_t st) {
+  if ((post & kPostPrior) && !log_priors) {
+    SetError("amlike_nnet_compute: log-likelihoods asked for, but the net has no priors");
+    return AMLIKE_EINVAL;
+  }
+  // Jobs: as many full rounds of 256-row jobs as the CUs take evenly, then the rest in equal
+  // shares (multiples of 32 rows) so that the last round is short everywhere.
+  int cus = std::max(1, NumComputeUnits());
+  if (const char *e = getenv("AMLIKE_NNET_OUT_CUS")) cus = std::max(1, atoi(e));  // testing aid: job shapes of a smaller chip
+  OutJobs jobs;
+  jobs.nbig = (rows / 256 / cus) * cus;
+  const int rest = rows - jobs.nbig * 256;
+  int nsmall = 0;
+  jobs.small = 256;
+  if (rest > 0) {
+    const int per = RoundUp((rest + cus - 1) / cus, 32);
+    jobs.small = per > 128 ? 256 : per;
+    nsmall = (rest + jobs.small - 1) / jobs.small;
+  }
+  const int grid = jobs.nbig + nsmall;
+  const size_t wplane = (size_t)s.out_dim * (s.Kp / 8);
+  const int npl = s.f16 ? 2 : 3;
+  const size_t smem = (size_t)kOutRing * npl * 2 * (s.Kp / 16) * 32 * sizeof(uint4) + 4 * 64 * sizeof(float);
+#define AMLIKE_OUT_LAUNCH(KS, PREC)                                                                     \
+  do {                                                                                                  \
+    AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nnet_out_softmax_kernel<KS, PREC>),   \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));             \
+    hipLaunchKernelGGL((nnet_out_softmax_kernel<KS, PREC>), dim3(grid), dim3(256), smem, st, xp, xplane, \
+                       s.d_wpo, wplane, s.d_bias, log_priors, y, ldy, rows, s.out_dim, post, scale, jobs); \
+  } while (0)
+  if (s.Kp == 208 && s.f16) AMLIKE_OUT_LAUNCH(13, 1);
+  else if (s.Kp == 208) AMLIKE_OUT_LAUNCH(13, 0);
+  else AMLIKE_OUT_LAUNCH(19, 1);
+#undef AMLIKE_OUT_LAUNCH
+  AMLIKE_HIP(hipGetLastError());
+  return AMLIKE_OK;
 }
 
 static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *utt_rows,
@@ -1550,6 +1894,37 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       which ^= 1;
       ++si;  // the p-norm stage is done
       continue;
+    } else if (s.kind == AMLIKE_AFFINE && FusedOutputApplies(n, si, d_out, ldo, post)) {
+      // the net's last affine layer and its softmax in one kernel: [rows x N] is written once
+      const Stage &sm = n->stages[si + 1];
+      (void)sm;
+      const size_t pstride = (size_t)cur_rows * s.Kp;
+      rc = n->ws_planes.Reserve(3 * pstride * sizeof(unsigned short));
+      if (rc != AMLIKE_OK) return rc;
+      unsigned short *pbase = static_cast<unsigned short *>(n->ws_planes.ptr);
+      if (!planes_ready) {
+        if (cur_ld < s.Kp || (cur_ld & 3) || (reinterpret_cast<uintptr_t>(cur) & 15)) {
+          SetError("amlike_nnet_compute: internal layout error before the output layer");
+          return AMLIKE_EINVAL;
+        }
+        Planes xp{pbase, pstride, s.Kp};
+        const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
+        if (s.f16)
+          hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld, s.in_dim,
+                             (int)cur_rows, xp, -1, nullptr, 0);
+        else
+          hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld, s.in_dim,
+                             (int)cur_rows, xp, -1, nullptr, 0);
+        AMLIKE_HIP(hipGetLastError());
+      }
+      planes_ready = 0;
+      rc = LaunchOutSoftmax(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, n->d_log_priors, d_out, ldo,
+                            (int)cur_rows, post, prob_scale, st);
+      if (rc != AMLIKE_OK) return rc;
+      cur = d_out;
+      cur_ld = ldo;
+      ++si;  // the softmax stage is done
+      continue;
     } else if (s.kind == AMLIKE_AFFINE) {
       if (cur_ld < s.Kp || (cur_ld & 3) || (reinterpret_cast<uintptr_t>(cur) & 15)) {
         SetError("amlike_nnet_compute: internal layout error before an affine stage");
@@ -1764,9 +2139,15 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
         if (e == hipSuccess) e = hipMalloc(&s.d_wp, wp.size() * sizeof(uint16_t));
         if (e == hipSuccess)
           e = hipMemcpy(s.d_wp, wp.data(), wp.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc(&s.d_bias, c.output_dim * sizeof(float));
-        if (e == hipSuccess)
-          e = hipMemcpy(s.d_bias, c.bias, c.output_dim * sizeof(float), hipMemcpyHostToDevice);
+        {
+          // padded to whole 32-unit tiles with -inf: a padding unit then has score -inf in the
+          // fused output-layer kernel (no share in the softmax sum); the other kernels stop at out_dim
+          std::vector<float> bpad(RoundUp(c.output_dim, 32), -INFINITY);
+          std::copy(c.bias, c.bias + c.output_dim, bpad.begin());
+          if (e == hipSuccess) e = hipMalloc(&s.d_bias, bpad.size() * sizeof(float));
+          if (e == hipSuccess)
+            e = hipMemcpy(s.d_bias, bpad.data(), bpad.size() * sizeof(float), hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) {
           SetError("amlike_nnet_create: %s", hipGetErrorString(e));
           rc = e == hipErrorOutOfMemory ? AMLIKE_EOOM : AMLIKE_EHIP;
@@ -1867,11 +2248,11 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
     std::vector<float>().swap(st.h_b);
   }
   if (rc == AMLIKE_OK && priors && num_priors > 0) {
-    std::vector<float> lp(num_priors);
+    std::vector<float> lp(RoundUp(num_priors, 32), 0.0f);  // padded to whole 32-unit tiles
     for (int i = 0; i < num_priors; ++i) lp[i] = logf(priors[i]);
-    hipError_t e = hipMalloc(&n->d_log_priors, num_priors * sizeof(float));
+    hipError_t e = hipMalloc(&n->d_log_priors, lp.size() * sizeof(float));
     if (e == hipSuccess)
-      e = hipMemcpy(n->d_log_priors, lp.data(), num_priors * sizeof(float), hipMemcpyHostToDevice);
+      e = hipMemcpy(n->d_log_priors, lp.data(), lp.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       SetError("amlike_nnet_create: %s", hipGetErrorString(e));
       rc = AMLIKE_EHIP;

@@ -463,6 +463,78 @@ def test_threads_sharing_one_handle_and_threads_with_their_own(amlike_device):
         np.testing.assert_array_equal(got, want[i])
 
 
+def test_two_threads_on_two_streams_of_one_handle_device_pointers(amlike_device):
+    """Device-pointer calls on ONE handle from two threads, each with a stream of its own: the
+    library keeps separate working memory per stream, so the launches may overlap on the GPU and
+    every result still carries the bits of a lone call.  Covers the split-pdf partial sums, the
+    repair list of the differenced kernel and the pruned path (the buffers that used to be shared)."""
+    import threading
+    import torch
+    m = synth.make_gmm(39, 120, 2600, seed=83)
+    big = synth.make_gmm(39, 1, 700, seed=84)  # a pdf wide enough to be split over several waves
+    mm = {k: np.concatenate([m[k], big[k]]) for k in ("weights", "means_invvars", "inv_vars")}
+    mm["pdf_offsets"] = np.concatenate([m["pdf_offsets"], [m["pdf_offsets"][-1] + 700]]).astype(np.int32)
+    am = gmm.AmDiagGmm(mm["weights"], mm["means_invvars"], mm["inv_vars"], mm["pdf_offsets"])
+    P = am.NumPdfs()
+    sizes = [[3000, 517, 2048, 64], [33, 4100, 1000, 2500]]
+    feats = [[torch.from_numpy(synth.make_feats(m, T, seed=100 + 10 * t + i)).cuda() for i, T in enumerate(sizes[t])]
+             for t in range(2)]
+    prune = [-1.0, 8.0]
+
+    def score(f, stream, pr):
+        out = torch.empty((f.shape[0], P), dtype=torch.float32, device="cuda")
+        am.LogLikelihoodsDevice(f.data_ptr(), f.shape[0], f.stride(0), f.shape[1], out.data_ptr(), P,
+                                stream=stream, log_sum_exp_prune=pr)
+        return out
+
+    # what a lone call gives
+    want = [[[score(f, None, pr) for pr in prune] for f in feats[t]] for t in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [[], []]
+    errors = []
+    start = threading.Barrier(2)
+
+    def work(t):
+        try:
+            start.wait()
+            for rep in range(6):
+                for f in feats[t]:
+                    got[t].append([score(f, streams[t].cuda_stream, pr) for pr in prune])
+            streams[t].synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for t in range(2):
+        assert len(got[t]) == 6 * len(feats[t])
+        for k, pair in enumerate(got[t]):
+            for j in range(2):
+                assert torch.equal(pair[j], want[t][k % len(feats[t])][j]), (t, k, j)
+
+
+def test_pruned_path_beyond_65535_frames_in_one_chunk(amlike_device):
+    """A small model with many frames: the pruned log-sum-exp pass covers them in launches the
+    grid can hold (one block row per frame)."""
+    m = synth.make_gmm(13, 4, 40, seed=85)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    T = 70001
+    feats = synth.make_feats(m, T, seed=86)
+    got = am.LogLikelihoods(feats, log_sum_exp_prune=50.0)
+    want = am.LogLikelihoods(feats)
+    assert got.shape == (T, 4)
+    np.testing.assert_allclose(got, want, atol=1e-3)
+    gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
+    tail, _ = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"], feats[-3:])
+    np.testing.assert_allclose(got[-3:], tail, atol=1e-3)
+
+
 @pytest.mark.parametrize("dim,P,G,T", [(100, 12, 150, 70), (72, 30, 300, 5), (117, 3, 10, 200)])
 def test_dimensions_beyond_the_fused_kernels(amlike_device, dim, P, G, T):
     """Feature dimensions above 64 have no fused kernel; the model is scored through the

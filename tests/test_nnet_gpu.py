@@ -210,3 +210,32 @@ def test_normalised_rows_written_straight_as_operand_planes(amlike_device, name,
     np.testing.assert_allclose(direct, two_pass, rtol=2e-5, atol=2e-5)
     want = oracle.nnet_compute(comps, priors, x, True, nnet.LOGLIKES, 1.0)
     assert np.abs(direct - want).max() < 1e-3
+
+
+@pytest.mark.parametrize("cus,rows", [("0", 300), ("2", 1000), ("3", 1000), ("1", 70)])
+@pytest.mark.parametrize("mode", [nnet.POSTERIORS, nnet.LOG, nnet.LOGLIKES])
+def test_output_layer_and_softmax_in_one_kernel(amlike_device, cus, rows, mode, monkeypatch):
+    """The fused output-layer + softmax kernel (k = 200, 8600 units) against the separate GEMM and
+    softmax kernels and against the oracle, over the job shapes it cuts the rows into: 256-row jobs
+    with 64 rows per wave, short jobs with 32 rows per wave, ragged last jobs (AMLIKE_NNET_OUT_CUS
+    makes the host plan jobs as for a chip with that many compute units)."""
+    if cus != "0":
+        monkeypatch.setenv("AMLIKE_NNET_OUT_CUS", cus)
+    comps, priors = synth.make_pnorm_nnet(seed=780)
+    x = np.random.default_rng(41).normal(size=(rows, 40)).astype(np.float32)
+    net = nnet.AmNnet(comps, priors)
+    got = net.Compute(x, mode=mode, prob_scale=0.9)
+    net.close()
+    monkeypatch.setenv("AMLIKE_NNET_NO_FUSED_OUT", "1")
+    net2 = nnet.AmNnet(comps, priors)
+    unfused = net2.Compute(x, mode=mode, prob_scale=0.9)
+    net2.close()
+    tol = 1e-5 if mode == nnet.POSTERIORS else 1e-3
+    assert np.isfinite(got).all()
+    assert np.abs(got - unfused).max() < tol
+    if rows <= 300:
+        want = oracle.nnet_compute(comps, priors, x, True, mode, 0.9)
+        assert np.abs(got - want).max() < tol
+        assert (got.argmax(1) == want.argmax(1)).mean() >= 0.9999
+    if mode == nnet.POSTERIORS:
+        assert np.allclose(got.sum(1), 1.0, atol=1e-4)

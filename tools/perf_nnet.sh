@@ -1,7 +1,7 @@
 # Per-kernel timing of the nnet2 p-norm forward (one bench step set under rocprofv3).
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_n
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_n -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 > $GRAFT_REPO_ROOT/gpurun_out/prof_n.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_n -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-to-host --steps 3 > $GRAFT_REPO_ROOT/gpurun_out/prof_n.log 2>&1
 grep -i "nnet" $GRAFT_REPO_ROOT/gpurun_out/prof_n/*/*kernel_stats.csv | cut -c1-60,150-260
 python3 - <<PY
 import csv,glob,os,json
