@@ -1049,13 +1049,97 @@ __global__ void __launch_bounds__(256)
 // output stores) is interleaved with the matrix instructions of tile t.
 // A job = up to 256 consecutive rows (64 per wave, FT = 2) or up to 128 (32 per wave, FT = 1);
 // the host cuts the rows into jobs so that the last round of jobs is short on every CU
-// instead of long on a few.
-constexpr int kOutRing = 3;
+// instead of long on a few, and lets half of the CUs start with a short job: the second sweep
+// is bound by the writes (measured: 2.3 us per tile without its stores, 3.3 us with them,
+// whatever their address pattern), the first writes nothing, and from then on the two halves
+// of the chip are in different sweeps.
+// Measured on the swbd shape (k = 200, 8600 units, 218.5 k rows): 4.9 ms against 6.8 ms for
+// the separate GEMM and softmax kernels; matrix instructions alone 3.2 ms.
+constexpr int kOutSideRing = 8;  // (32 biases, 32 log priors) of a tile, kept longer than the tile
+// Result tiles on their way to memory: per wave 64 rows x 32 values, rows 36 floats apart
+constexpr int kOutStagePitch = 36, kOutStageBytes = 4 * 64 * kOutStagePitch * 4;
+#ifndef AMLIKE_OUT_RING_MAX
+#define AMLIKE_OUT_RING_MAX 5
+#endif
+// W tiles of the LDS ring: as many as fit, up to AMLIKE_OUT_RING_MAX
+__host__ __device__ constexpr int OutRingTiles(int KS, int PREC) {
+  const int tile = (PREC ? 2 : 3) * 2 * KS * 32 * 16, room = 160 * 1024 - kOutSideRing * 256 - kOutStageBytes;
+  return room / tile >= AMLIKE_OUT_RING_MAX ? AMLIKE_OUT_RING_MAX : room / tile;
+}
 // An empty volatile asm that takes and returns `x` in a vector register: instructions that
 // produce x stay before it and instructions that use x stay after it in program order.
 __device__ __forceinline__ void pin_order(float &x) {
 #if __HIP_DEVICE_COMPILE__  // the host pass cannot parse the vector-register constraint
   asm volatile("" : "+v"(x));
+#endif
+}
+// Waits until at most `N` of the wave's vector-memory instructions are outstanding.
+template <int N>
+__device__ __forceinline__ void wait_vector_memory_but() {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+// LDS reads the compiler does not see (it would otherwise order every read of memory that
+// global_load ... lds may write behind ALL such loads in flight): 16 bytes at `p`, valid after
+// lds_hidden_wait on the same variables.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_hidden_read(f32x4 &v, const float *p) {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p));
+#endif
+}
+template <int OFFSET>
+__device__ __forceinline__ void lds_hidden_read_at(f32x4 &v, unsigned addr) {  // byte address + constant
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET));
+#endif
+}
+template <int OFFSET>
+__device__ __forceinline__ void lds_hidden_write_at(unsigned addr, const f32x4 &v) {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFFSET) : "memory");
+#endif
+}
+__device__ __forceinline__ void lds_hidden_wait1(f32x4 &a) {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a));
+#endif
+}
+__device__ __forceinline__ void lds_hidden_wait(f32x4 (&a)[4], f32x4 (&b)[4]) {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+#endif
+}
+// The fp16 matrix instruction, acc += a . b, as the assembler sees it: the accumulator and
+// (B_AGPR) the b operand are kept in the accumulation half of the register file, which the
+// compiler's own allocation only uses as overflow space, with a copy per use.  The compiler
+// does not know these are matrix instructions: the caller keeps the required distance between
+// them and vector instructions that write their operands or read their result.
+template <bool B_AGPR, bool AFTER_INIT>
+__device__ __forceinline__ void mfma_f16_asm(f32x16 &acc, const bf16x8_t &a, const bf16x8_t &b) {
+#if __HIP_DEVICE_COMPILE__
+  if constexpr (B_AGPR) {
+    if constexpr (AFTER_INIT) asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(b));
+  } else {
+    if constexpr (AFTER_INIT) asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  }
+#endif
+}
+// Covers the distance a vector instruction must keep behind a matrix instruction whose result it reads.
+__device__ __forceinline__ void mfma_result_gap() {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("s_nop 15\n\ts_nop 15");
+#endif
+}
+// The workgroup barrier alone: unlike __syncthreads() it does not wait for the wave's
+// outstanding global_load ... lds (the caller waits for exactly the ones that matter).
+__device__ __forceinline__ void barrier_only() {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("s_barrier" ::: "memory");
 #endif
 }
 template <int N, int I = 0, class F>
@@ -1065,9 +1149,13 @@ __device__ __forceinline__ void static_for(F &&f) {  // f(integral_constant<int,
     static_for<N, I + 1>(f);
   }
 }
+#ifdef AMLIKE_OUT_STAMPS  // diagnostic build: clock ticks of the two sweeps of job 0, printed per launch
+__device__ unsigned long long g_out_stamps[8];
+#endif
 struct OutJobs {
-  int nbig;    // jobs of 256 rows, first
-  int small;   // rows per remaining job (multiple of 32, <= 128 for FT = 1)
+  int nbig;    // jobs of 256 rows
+  int small;   // rows per remaining job (multiple of 32, <= 128 for FT = 1); their rows follow the big jobs'
+  int lead;    // small jobs that go first (blocks 0 .. lead-1), before the big ones
 };
 
 template <int KS, int PREC>
@@ -1078,50 +1166,62 @@ __global__ void __launch_bounds__(256, 1)
                             int N, int post, float scale, OutJobs jobs) {
   constexpr int NPL = PREC ? 2 : 3, NPROD = PREC ? 3 : 6;
   constexpr int kTileU4 = NPL * 2 * KS * 32;  // uint4 per staged W tile: [plane][octet][32 units]
+  constexpr int kOutRing = OutRingTiles(KS, PREC), kLead = kOutRing - 1;  // tile seq + kLead is requested in step seq
+  constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_o[];
   uint4 *s_w = reinterpret_cast<uint4 *>(smem_o);
-  // beside the W ring, a ring of 4 x (32 biases, 32 log priors): a tile's log priors are still
-  // read one step after the tile itself (by the stores), so they outlive its W slot by a step
   float *s_bp = reinterpret_cast<float *>(s_w + kOutRing * kTileU4);
+  float *s_stage = s_bp + kOutSideRing * 64;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 31, h = lane >> 5;
   int row0, nrows;
-  if ((int)blockIdx.x < jobs.nbig) {
-    row0 = blockIdx.x * 256;
+  const int b = blockIdx.x;
+  if (b >= jobs.lead && b < jobs.lead + jobs.nbig) {
+    row0 = (b - jobs.lead) * 256;
     nrows = 256;
   } else {
-    row0 = jobs.nbig * 256 + ((int)blockIdx.x - jobs.nbig) * jobs.small;
+    row0 = jobs.nbig * 256 + (b < jobs.lead ? b : b - jobs.nbig) * jobs.small;
     nrows = min(jobs.small, M - row0);
   }
   if (nrows <= 0) return;
   const int ntile = (N + 31) >> 5;
   const int total = 2 * ntile;  // W tiles to stream: both sweeps
+  const float *prior_src = logprior_pad ? logprior_pad : bias_pad;
 
-  auto run = [&](auto ft_tag) __attribute__((always_inline)) {
+  // W tile `seq % ntile` travels global -> LDS ring slot seq % kOutRing without passing through
+  // registers (global_load ... lds), in pieces of 1 KiB (64 lanes x 16 bytes: two octets of one
+  // plane for 32 units) dealt round-robin to the 4 waves; its biases and log priors go to
+  // slot seq % kOutSideRing of the side ring.  Every wave issues exactly kMine + 1 of these
+  // loads per tile (a wave short of a piece repeats the last one), so "all but the newest
+  // kMine + 1 vector-memory instructions have finished" means: every tile requested before the
+  // newest has landed.
+  constexpr int kPieces = NPL * KS, kMine = (kPieces + 3) / 4;
+  // (the blocks take the pieces of a tile in different orders: they all want the same tile at
+  // about the same time, and should not all want the same piece of it)
+  const int rot = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 7u) % (4u * kMine)));
+  auto request = [&](int seq) __attribute__((always_inline)) {
+    const int n0 = (seq % ntile) << 5;
+    uint4 *dst = s_w + (seq % kOutRing) * kTileU4;
+#pragma unroll
+    for (int i = 0; i < kMine; ++i) {
+      const int piece = min((w + 4 * i + rot) % (4 * kMine), kPieces - 1);
+      const int q = piece / KS, op = piece - q * KS;  // plane, octet pair
+      const uint4 *src = Wp + (size_t)q * wplane + (size_t)(2 * op + h) * N + min(n0 + li, N - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(dst + piece * 64), 16, 0, 0);
+    }
+    const float *bsrc = (h ? prior_src : bias_pad) + n0 + li;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)bsrc,
+                                     (__attribute__((address_space(3))) void *)(s_bp + (seq % kOutSideRing) * 64),
+                                     4, 0, 0);
+  };
+
+  auto run = [&](auto ft_tag, auto logm_tag) __attribute__((always_inline)) {
     constexpr int FT = decltype(ft_tag)::value;
-    // W tile `seq % ntile` travels global -> registers (fetch, at the start of a step) -> LDS ring
-    // slot seq % kOutRing (commit, at the end of the step): pieces of 1 KiB (64 lanes x 16 bytes:
-    // two octets of one plane for 32 units), dealt round-robin to the 4 waves.
-    constexpr int kPieces = NPL * KS, kMine = (kPieces + 3) / 4;
-    bf16x8_t wreg[kMine];
-    float breg = 0.0f;  // wave 3: lanes 0-31 a bias, lanes 32-63 a log prior of the tile
-    auto fetch = [&](int seq) __attribute__((always_inline)) {
-      const int n0 = (seq % ntile) << 5;
-#pragma unroll
-      for (int i = 0; i < kMine; ++i) {
-        const int piece = min(w + 4 * i, kPieces - 1);
-        const int q = piece / KS, op = piece - q * KS;  // plane, octet pair
-        wreg[i] = __builtin_bit_cast(bf16x8_t, Wp[(size_t)q * wplane + (size_t)(2 * op + h) * N + min(n0 + li, N - 1)]);
-      }
-      if (w == 3) breg = h ? logprior_pad[n0 + li] : bias_pad[n0 + li];
-    };
-    auto commit = [&](int seq) __attribute__((always_inline)) {
-      uint4 *dst = s_w + (seq % kOutRing) * kTileU4;
-#pragma unroll
-      for (int i = 0; i < kMine; ++i)
-        if (w + 4 * i < kPieces) dst[(w + 4 * i) * 64 + lane] = __builtin_bit_cast(uint4, wreg[i]);
-      if (w == 3) s_bp[(seq & 3) * 64 + lane] = breg;
-    };
+    constexpr bool LOGM = decltype(logm_tag)::value;  // log-probabilities (floored) or posteriors
+    constexpr int NPF = NPROD * FT;    // matrix instructions per k-step
+    constexpr int NMF = KS * NPF;      // per W tile
+    constexpr int NE = 16 * FT;        // values of a finished tile per lane
     const int wrow0 = row0 + w * 32 * FT;  // this wave's first row
     // X fragments, resident: [frame tile][k-step][plane]
     bf16x8_t xf[FT][KS][NPL];
@@ -1134,6 +1234,7 @@ __global__ void __launch_bounds__(256, 1)
         for (int q = 0; q < NPL; ++q)
           xf[f][ks][q] = __builtin_bit_cast(bf16x8_t, Xp[(size_t)q * xplane + (size_t)(2 * ks + h) * M + r]);
     }
+    // running softmax statistics per row, in log2 units: maximum and sum of 2^(z log2e - max)
     float mx[FT], sm[FT], logz[FT];
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
@@ -1141,58 +1242,112 @@ __global__ void __launch_bounds__(256, 1)
       sm[f] = 0.0f;
       logz[f] = 0.0f;
     }
-    // the first two tiles of the stream
-    fetch(0);
-    commit(0);
-    fetch(1);
-    commit(1);
+    // of the lane's 16 units: the biases of the next tile, the log priors of the tile finished last
+    f32x4 bnext[4], lpold[4];
+    const float pscale = (post & kPostPrior) ? scale : 1.0f, nscale = (post & kPostPrior) ? -scale : 0.0f;
+    static_for<kLead>([&](auto t) __attribute__((always_inline)) { request(decltype(t)::value); });
 
-    // sweep 1, the vector work on one finished tile: running (max, sum) of its 16 units per
-    // lane.  part 0: the tile's maximum and the rescaling of the sum; parts 1..4: four units each
-    auto stats_part = [&](const f32x16 (&acc)[FT], int part) __attribute__((always_inline)) {
+    // Sweep 1, the vector work on one finished tile, cut into units that go between the matrix
+    // instructions of the next tile.  Units 0 .. FT-1: a frame tile's maximum and the
+    // rescaling of its sum.  Units FT .. FT+NE+1: a three-stage pipeline over the NE values
+    // (scaled difference, 2^x, accumulate), one value entering per unit.
+    constexpr int kStatUnits = FT + NE + 2;
+    float st_t[NE], st_e[NE];
+    auto stats_unit = [&](const f32x16 (&acc)[FT], auto u_tag) __attribute__((always_inline)) {
+      constexpr int u = decltype(u_tag)::value;
+      if constexpr (u < FT) {
+        constexpr int f = u;
+        float m = fmaxf(acc[f][0], acc[f][1]);
 #pragma unroll
-      for (int f = 0; f < FT; ++f) {
-        if (part == 0) {
-          float m = acc[f][0];
-#pragma unroll
-          for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[f][r]);
-          const float mn = fmaxf(mx[f], m);
-          sm[f] *= __expf(mx[f] - mn);  // exp(-inf) = 0 on the first tile, where sm is 0 too
-          mx[f] = mn;
-        } else {
-#pragma unroll
-          for (int r = 4 * (part - 1); r < 4 * part; ++r) sm[f] += __expf(acc[f][r] - mx[f]);
-        }
-        pin_order(sm[f]);  // the part stays in the k-step it was written in
+        for (int r = 2; r < 16; r += 2) m = fmaxf(m, fmaxf(acc[f][r], acc[f][r + 1]));
+        const float mn = fmaxf(mx[f], m * kLog2e);
+        sm[f] *= __builtin_amdgcn_exp2f(mx[f] - mn);  // 2^(-inf) = 0 on the first tile, where sm is 0 too
+        mx[f] = mn;
+        pin_order(sm[f]);
         pin_order(mx[f]);
+      } else {
+        constexpr int i = u - FT;  // value i enters; i - 1 is exponentiated; i - 2 is added
+        if constexpr (i < NE) {
+          st_t[i] = fmaf(acc[i % FT][i / FT], kLog2e, -mx[i % FT]);
+          pin_order(st_t[i]);
+        }
+        if constexpr (i >= 1 && i - 1 < NE) {
+          st_e[i - 1] = __builtin_amdgcn_exp2f(st_t[i - 1]);
+          pin_order(st_e[i - 1]);
+        }
+        if constexpr (i >= 2) {
+          sm[(i - 2) % FT] += st_e[i - 2];
+          pin_order(sm[(i - 2) % FT]);
+        }
       }
     };
-    // sweep 2, the vector work on one finished tile: units 8 part + 4 h .. + 3 of tile n0
-    auto store_part = [&](const f32x16 (&acc)[FT], int n0, int old_seq, int part) __attribute__((always_inline)) {
-      if (part >= 4) return;
-      const int c = n0 + 8 * part + 4 * h;
-      if (c >= N) return;
-      float4 lp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (post & kPostPrior)
-        lp = *reinterpret_cast<const float4 *>(s_bp + (old_seq & 3) * 64 + 32 + 8 * part + 4 * h);
+    // Sweep 2, the vector work on one finished tile.  The matrix instruction leaves a lane with 4
+    // consecutive values of ONE row per group (part, f): stored from there, an instruction would
+    // touch 32 rows with 32 bytes each.  So the finished values first go to the wave's staging
+    // tile in LDS (16 "group" operations of four stages each per frame tile: log softmax; floor or
+    // posterior; minus log prior, times scale; 16-byte LDS write) and come back row-wise, 8
+    // lanes to a row of 128 bytes, in 4 "chunks" of 8 rows per frame tile (a read operation and,
+    // a little later, a store operation).  Order: the groups of frame tile 0; the groups of frame
+    // tile 1 interleaved with the chunks of tile 0; the chunks of the last tile.
+    constexpr int kStoreOps = 16 * FT + 8 * FT;
+    f32x4 sv, rd[2];
+    const unsigned stage_w = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)s_stage +
+                             (unsigned)w * (64 * kOutStagePitch * 4);
+    const unsigned st_waddr = stage_w + (li * kOutStagePitch + 4 * h) * 4;                  // group writes
+    const unsigned st_raddr = stage_w + ((lane >> 3) * kOutStagePitch + 4 * (lane & 7)) * 4;  // chunk reads
+    // the lane's 16 bytes of a chunk in Y, relative to the job's first row and the tile's first column
+    const unsigned st_yoff = ((unsigned)(w * 32 * FT + (lane >> 3)) * (unsigned)ldy + 4u * (lane & 7)) * 4u;
+    char *const yjob = reinterpret_cast<char *>(Y + (size_t)row0 * ldy);
+    auto group_op = [&](const f32x16 (&acc)[FT], auto f_tag, auto k_tag) __attribute__((always_inline)) {
+      constexpr int f = decltype(f_tag)::value, k = decltype(k_tag)::value, part = k / 4, stage = k % 4;
+      if constexpr (stage == 0) {
 #pragma unroll
-      for (int f = 0; f < FT; ++f) {
-        const int row = wrow0 + 32 * f + li;
-        float v[4];
+        for (int e = 0; e < 4; ++e) sv[e] = acc[f][4 * part + e] - logz[f];
+      } else if constexpr (stage == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float lsm = acc[f][4 * part + i] - logz[f];  // log softmax
-          if (post & kPostFloorLog) v[i] = fmaxf(lsm, -46.051701859880914f);  // log(1e-20)
-          else v[i] = floor_1e20(__expf(lsm));
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (LOGM) sv[e] = fmaxf(sv[e], -46.051701859880914f);  // log(1e-20)
+          else sv[e] = floor_1e20(__expf(sv[e]));
         }
-        if (post & kPostPrior) {
-          v[0] = (v[0] - lp.x) * scale;
-          v[1] = (v[1] - lp.y) * scale;
-          v[2] = (v[2] - lp.z) * scale;
-          v[3] = (v[3] - lp.w) * scale;
+      } else if constexpr (stage == 2) {
+        sv = sv * pscale + lpold[part];  // lpold: -log prior x scale (or 0)
+      } else {
+        lds_hidden_write_at<((32 * f) * kOutStagePitch + 8 * part) * 4>(st_waddr, sv);
+      }
+      if constexpr (stage < 3) {
+#if __HIP_DEVICE_COMPILE__
+        asm volatile("" : "+v"(sv));
+#endif
+      }
+    };
+    auto chunk_op = [&](int n0, auto f_tag, auto j_tag) __attribute__((always_inline)) {
+      constexpr int f = decltype(f_tag)::value, j = decltype(j_tag)::value;
+      constexpr int is_store[8] = {0, 0, 1, 0, 1, 0, 1, 1}, chunk_of[8] = {0, 1, 0, 2, 1, 3, 2, 3};
+      constexpr int c = chunk_of[j], row = 32 * f + 8 * c;
+      if constexpr (!is_store[j]) {
+        lds_hidden_read_at<row * kOutStagePitch * 4>(rd[c & 1], st_raddr);
+      } else {
+        lds_hidden_wait1(rd[c & 1]);
+#ifndef AMLIKE_OUT_NOSTORE  // (timing experiment: nothing is written)
+        if (w * 32 * FT + row + (lane >> 3) < nrows && n0 + 4 * (lane & 7) < N) {
+          const float4 v = make_float4(rd[c & 1][0], rd[c & 1][1], rd[c & 1][2], rd[c & 1][3]);
+          *reinterpret_cast<float4 *>(yjob + ((size_t)row * ldy + n0) * 4 + st_yoff) = v;
         }
-        if (row < row0 + nrows)
-          *reinterpret_cast<float4 *>(Y + (size_t)row * ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
+      }
+    };
+    auto store_op = [&](const f32x16 (&acc)[FT], int n0, auto i_tag) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_tag)::value;
+      using F0 = std::integral_constant<int, 0>;
+      using FL = std::integral_constant<int, FT - 1>;
+      if constexpr (i < 16) {
+        group_op(acc, F0(), std::integral_constant<int, i>());
+      } else if constexpr (FT == 2 && i < 40) {
+        constexpr int i2 = i - 16, blk = i2 / 3, pos = i2 % 3;
+        if constexpr (pos < 2) group_op(acc, FL(), std::integral_constant<int, 2 * blk + pos>());
+        else chunk_op(n0, F0(), std::integral_constant<int, blk>());
+      } else {
+        chunk_op(n0, FL(), std::integral_constant<int, i - (FT == 2 ? 40 : 16)>());
       }
     };
 
@@ -1211,21 +1366,31 @@ __global__ void __launch_bounds__(256, 1)
       for (int q = 0; q < NPL; ++q)
         wf[slot][q] = __builtin_bit_cast(bf16x8_t, wt[(q * 2 * KS + 2 * ks + h) * 32 + li]);
     };
-    float4 bnext[4];  // the biases of the lane's 16 units of the next tile
-    auto load_bias = [&](int seq) __attribute__((always_inline)) {
+    // requests the biases of tile seq + 1 and the log priors of tile seq (hidden reads)
+    auto load_side = [&](int seq) __attribute__((always_inline)) {
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4)
-        bnext[q4] = *reinterpret_cast<const float4 *>(s_bp + (seq & 3) * 64 + 8 * q4 + 4 * h);
+      for (int q4 = 0; q4 < 4; ++q4) {
+        lds_hidden_read(bnext[q4], s_bp + ((seq + 1) % kOutSideRing) * 64 + 8 * q4 + 4 * h);
+        lds_hidden_read(lpold[q4], s_bp + (seq % kOutSideRing) * 64 + 32 + 8 * q4 + 4 * h);
+      }
     };
     // One step of the stream: the matrix instructions of W tile seq into acc_new (initialised
     // with the bias), with the vector work of the previous tile (acc_old; kind 0: none, 1: sweep-1
-    // statistics, 2: sweep-2 stores of tile old_n0) spread between them.  On entry the fragments
-    // of k-steps 0 .. kAhead-1 of tile seq and its biases have been requested.
+    // statistics, 2: sweep-2 stores of tile old_n0) placed between them unit by unit.  On entry
+    // tiles seq and seq + 1 are in LDS, tile seq + 2 is on its way, and the fragments of k-steps
+    // 0 .. kAhead-1 of tile seq and its biases have been requested from LDS.
+    // The k-step in which tile seq + kLead is requested: the first, so that the step's stores are
+    // all younger than the request and the wait at the end of the step (all but the newest
+    // loads and stores) does not wait for any of them.
+    constexpr int kRequestKs = 0;
     auto step = [&](int seq, f32x16 (&acc_new)[FT], const f32x16 (&acc_old)[FT], auto kind_tag,
                     int old_n0) __attribute__((always_inline)) {
       constexpr int kKind = decltype(kind_tag)::value;
-      const bool more = seq + 2 < total;
-      if (more) fetch(seq + 2);
+      lds_hidden_wait(bnext, lpold);
+      if constexpr (kKind == 2) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) lpold[q4] = lpold[q4] * nscale;  // -log prior x scale (0 without priors)
+      }
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
 #pragma unroll
@@ -1244,39 +1409,64 @@ __global__ void __launch_bounds__(256, 1)
           load_frag(seq, std::integral_constant<int, (ks + kAhead) % KS>());
         } else {
           if (seq + 1 < total) load_frag(seq + 1, std::integral_constant<int, (ks + kAhead) % KS>());
-          if (ks == KS - 1 && seq + 1 < total) load_bias(seq + 1);
+          if (ks == KS - 1) load_side(seq);  // (past the last tile the biases read are not used)
         }
+#ifndef AMLIKE_OUT_NOFETCH  // (timing experiment: the W stream stops after its first tiles)
+        // (past the end of the stream the request wraps around: harmless, and it keeps the count
+        // of outstanding loads the same in every step)
+        if constexpr (ks == kRequestKs) request(seq + kLead);
+#endif
         constexpr int slot = ks == KS - 1 ? 3 : ks % 3;
-#pragma unroll
-        for (int which = 0; which < NPROD; ++which) {
+        static_for<NPF>([&](auto j_tag) __attribute__((always_inline)) {
+          constexpr int j = decltype(j_tag)::value, which = j / FT, f = j % FT, mi = ks * NPF + j;
           int pa, pb;
           product_parts<PREC>(which, pa, pb);
-#pragma unroll
-          for (int f = 0; f < FT; ++f)
+          if constexpr (PREC == 1) {
+            // frame tile 0's fragments live in the accumulation registers, tile 1's in the ordinary ones
+            if constexpr (f == 0) mfma_f16_asm<true, ks == 0 && j < FT>(acc_new[f], wf[slot][pa], xf[f][ks][pb]);
+            else mfma_f16_asm<false, ks == 0 && j < FT>(acc_new[f], wf[slot][pa], xf[f][ks][pb]);
+          } else {
             acc_new[f] = mfma16<PREC>(wf[slot][pa], xf[f][ks][pb], acc_new[f]);
-        }
-        if (kKind != 0) {
-          constexpr int kParts = 5;
-#pragma unroll
-          for (int part = (ks * kParts) / KS; part < ((ks + 1) * kParts) / KS; ++part) {
-            if (kKind == 1) stats_part(acc_old, part);
-            else store_part(acc_old, old_n0, seq - 1, part);
           }
-        }
-        // nothing moves across a k-step: the LDS reads stay kAhead k-steps ahead of their use
-        __builtin_amdgcn_sched_barrier(0);
+#ifndef AMLIKE_OUT_NOVEC  // (timing experiment: matrix instructions only)
+          if constexpr (kKind == 1) {
+            // the units spread evenly over the tile's matrix instructions
+            constexpr int u0 = (mi * kStatUnits + NMF - 1) / NMF, u1 = ((mi + 1) * kStatUnits + NMF - 1) / NMF;
+            static_for<u1 - u0>([&](auto d) __attribute__((always_inline)) {
+              stats_unit(acc_old, std::integral_constant<int, u0 + decltype(d)::value>());
+            });
+          } else if constexpr (kKind == 2) {
+            // over all k-steps but the last, which requests the next tile's log priors into lpold
+            constexpr int span = (KS - 1) * NPF;
+            if constexpr (mi < span) {
+              constexpr int u0 = (mi * kStoreOps + span - 1) / span, u1 = ((mi + 1) * kStoreOps + span - 1) / span;
+              static_for<u1 - u0>([&](auto d) __attribute__((always_inline)) {
+                store_op(acc_old, old_n0, std::integral_constant<int, u0 + decltype(d)::value>());
+              });
+            }
+          }
+#endif
+          // nothing moves across a matrix instruction and its share of the vector work
+          __builtin_amdgcn_sched_barrier(0);
+        });
       });
-      if (more) commit(seq + 2);
-      // every wave has committed its pieces of tile seq + 2 and has finished reading tile seq
-      __syncthreads();
+      // tile seq + 2 (requested kLead - 1.5 steps ago) has landed; every wave has finished
+      // reading tile seq
+      if constexpr (PREC == 1) mfma_result_gap();
+      wait_vector_memory_but<(kLead - 2) * (kMine + 1)>();
+      barrier_only();
     };
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>;
     f32x16 acc_a[FT], acc_b[FT];
-    __syncthreads();  // tiles 0 and 1 are in LDS
-    load_bias(0);
+    wait_vector_memory_but<(kLead - 2) * (kMine + 1)>();
+    barrier_only();  // tiles 0 and 1 are in LDS
+    load_side(-1);
     static_for<kAhead>([&](auto j) __attribute__((always_inline)) { load_frag(0, j); });
+#ifdef AMLIKE_OUT_STAMPS
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // sweep 1
     step(0, acc_a, acc_b, K0(), 0);
     bool in_a = true;  // which set holds the tile finished last
@@ -1288,17 +1478,20 @@ __global__ void __launch_bounds__(256, 1)
         in_a = true;
       }
     }
-#pragma unroll
-    for (int part = 0; part < 5; ++part) {
-      if (in_a) stats_part(acc_a, part);
-      else stats_part(acc_b, part);
-    }
+    static_for<kStatUnits>([&](auto u) __attribute__((always_inline)) {
+      if (in_a) stats_unit(acc_a, u);
+      else stats_unit(acc_b, u);
+    });
 #pragma unroll
     for (int f = 0; f < FT; ++f) {  // the two half-waves hold different units of the same rows
       const float om = __shfl_xor(mx[f], 32), os = __shfl_xor(sm[f], 32);
       const float mn = fmaxf(mx[f], om);
-      logz[f] = mn + __logf(sm[f] * __expf(mx[f] - mn) + os * __expf(om - mn));
+      const float tot = sm[f] * __builtin_amdgcn_exp2f(mx[f] - mn) + os * __builtin_amdgcn_exp2f(om - mn);
+      logz[f] = (mn + __log2f(tot)) * kLn2;
     }
+#ifdef AMLIKE_OUT_STAMPS
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+#endif
     // sweep 2
     step(ntile, acc_a, acc_b, K0(), 0);
     in_a = true;
@@ -1310,14 +1503,31 @@ __global__ void __launch_bounds__(256, 1)
         in_a = true;
       }
     }
+    lds_hidden_wait(bnext, lpold);
 #pragma unroll
-    for (int part = 0; part < 4; ++part) {
-      if (in_a) store_part(acc_a, (ntile - 1) << 5, total - 1, part);
-      else store_part(acc_b, (ntile - 1) << 5, total - 1, part);
+    for (int q4 = 0; q4 < 4; ++q4) lpold[q4] = lpold[q4] * nscale;
+    static_for<kStoreOps>([&](auto u) __attribute__((always_inline)) {
+      if (in_a) store_op(acc_a, (ntile - 1) << 5, u);
+      else store_op(acc_b, (ntile - 1) << 5, u);
+    });
+    wait_vector_memory_but<0>();  // no load may still be on its way into LDS when the block ends
+#ifdef AMLIKE_OUT_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      g_out_stamps[0] = c1 - c0;
+      g_out_stamps[1] = __builtin_readcyclecounter() - c1;
+      g_out_stamps[2] = r1 - r0;
+      g_out_stamps[3] = __builtin_amdgcn_s_memrealtime() - r1;
+      g_out_stamps[4] = ntile;
     }
+#endif
   };
-  if (nrows <= 128) run(std::integral_constant<int, 1>());
-  else run(std::integral_constant<int, 2>());
+  if (post & kPostFloorLog) {
+    if (nrows <= 128) run(std::integral_constant<int, 1>(), std::true_type());
+    else run(std::integral_constant<int, 2>(), std::true_type());
+  } else {
+    if (nrows <= 128) run(std::integral_constant<int, 1>(), std::false_type());
+    else run(std::integral_constant<int, 2>(), std::false_type());
+  }
 }
 
 // Softmax for rows wider than the register form holds: three passes over the row.
@@ -1585,10 +1795,16 @@ static int LaunchOutSoftmax(const Stage &s, const uint4 *xp, size_t xplane, cons
     jobs.small = per > 128 ? 256 : per;
     nsmall = (rest + jobs.small - 1) / jobs.small;
   }
+  // The second sweep is bound by the writes, the first writes nothing: half of the CUs start
+  // with a short job, so that from then on one half of the chip is in its first sweep while
+  // the other is in its second.
+  jobs.lead = jobs.nbig > 0 && jobs.small <= 128 ? std::min(nsmall, cus / 2) : 0;
+  if (getenv("AMLIKE_NNET_OUT_NO_STAGGER")) jobs.lead = 0;  // tuning aid
   const int grid = jobs.nbig + nsmall;
   const size_t wplane = (size_t)s.out_dim * (s.Kp / 8);
   const int npl = s.f16 ? 2 : 3;
-  const size_t smem = (size_t)kOutRing * npl * 2 * (s.Kp / 16) * 32 * sizeof(uint4) + 4 * 64 * sizeof(float);
+  const size_t smem = (size_t)OutRingTiles(s.Kp / 16, s.f16 ? 1 : 0) * npl * 2 * (s.Kp / 16) * 32 * sizeof(uint4) +
+                      kOutSideRing * 64 * sizeof(float) + kOutStageBytes;
 #define AMLIKE_OUT_LAUNCH(KS, PREC)                                                                     \
   do {                                                                                                  \
     AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nnet_out_softmax_kernel<KS, PREC>),   \
@@ -1601,6 +1817,15 @@ static int LaunchOutSoftmax(const Stage &s, const uint4 *xp, size_t xplane, cons
   else AMLIKE_OUT_LAUNCH(19, 1);
 #undef AMLIKE_OUT_LAUNCH
   AMLIKE_HIP(hipGetLastError());
+#ifdef AMLIKE_OUT_STAMPS
+  {
+    AMLIKE_HIP(hipStreamSynchronize(st));
+    unsigned long long hs[8];
+    if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_out_stamps), sizeof(hs)) == hipSuccess && hs[4])
+      fprintf(stderr, "out+softmax job 0: sweep 1 %.0f ticks/tile (%.3f us), sweep 2 %.0f ticks/tile (%.3f us), %llu tiles\n",
+              (double)hs[0] / hs[4], hs[2] * 0.01 / hs[4], (double)hs[1] / hs[4], hs[3] * 0.01 / hs[4], hs[4]);
+  }
+#endif
   return AMLIKE_OK;
 }
 

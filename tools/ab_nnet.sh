@@ -1,8 +1,9 @@
-# Per-kernel GEMM times of the nnet2 forward for several library builds (A/B on one box).
+# Per-kernel times of the nnet2 forward for several library builds (A/B on one box).
+# AB_ARGS: bench.py arguments that pick the workload (default: the small rm_tri1 one).
 cd /tmp && export TMPDIR=/tmp
 for l in "$@"; do
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_ab
-  AMLIKE_LIB_PATH=$GRAFT_REPO_ROOT/kaldi_amd/csrc/$l timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_ab -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 3 --config rm_tri1 --utts-per-gpu ${AB_UTTS:-40} > $GRAFT_REPO_ROOT/gpurun_out/prof_ab.log 2>&1 || exit 1
+  AMLIKE_LIB_PATH=$GRAFT_REPO_ROOT/kaldi_amd/csrc/$l timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_ab -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-to-host --steps 3 ${AB_ARGS:---config rm_tri1 --utts-per-gpu 40} > $GRAFT_REPO_ROOT/gpurun_out/prof_ab.log 2>&1 || exit 1
   echo "== $l"
   python3 - <<PY
 import csv,glob,os
