@@ -36,10 +36,17 @@ typedef struct amlike_nnet amlike_nnet_t; /* nnet2 forward pipeline resident in 
 
 /* ---- device / process ---------------------------------------------------- */
 
-/* Replaces CuDevice::SelectGpuId (cudamatrix/cu-device.cc:64-138): binds the
- * calling thread (and every handle created afterwards) to `device`.
- * Returns AMLIKE_ENODEV when no gfx950 device is visible. */
+/* Replaces CuDevice::SelectGpuId (cudamatrix/cu-device.cc:64-138): makes `device` the
+ * device on which the calling thread creates handles from now on (and the process's default
+ * for threads that never call it).  May be called for several devices, from one thread or
+ * from one thread per device: a handle stays on the device it was created on, and every
+ * call that takes a handle runs on the handle's device whatever thread makes it.
+ * Returns AMLIKE_ENODEV when `device` is not a visible gfx950 device. */
 int amlike_init(int device);
+
+/* The device a handle lives on. */
+int32_t amlike_gmm_device(const amlike_gmm_t *gmm);
+int32_t amlike_nnet_device(const amlike_nnet_t *nnet);
 
 /* Last error text of the calling thread (KALDI_ERR message analogue). */
 const char *amlike_last_error(void);
@@ -198,6 +205,7 @@ int amlike_xform_create(int32_t dim, int32_t left, int32_t right, const float *m
 int amlike_xform_destroy(amlike_xform_t *xf);
 int32_t amlike_xform_input_dim(const amlike_xform_t *xf);
 int32_t amlike_xform_output_dim(const amlike_xform_t *xf);
+int32_t amlike_xform_device(const amlike_xform_t *xf);
 
 /* Applies it to one utterance (host pointers, synchronous), followed -- when spk_mat is not
  * NULL -- by a second transform-feats pass with that [rows2 x cols2] matrix, the per-speaker

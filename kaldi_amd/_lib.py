@@ -48,6 +48,9 @@ def _declare(lib):
         "amlike_xform_destroy": (ctypes.c_int, [c_void_p]),
         "amlike_xform_input_dim": (c_int32, [c_void_p]),
         "amlike_xform_output_dim": (c_int32, [c_void_p]),
+        "amlike_xform_device": (c_int32, [c_void_p]),
+        "amlike_gmm_device": (c_int32, [c_void_p]),
+        "amlike_nnet_device": (c_int32, [c_void_p]),
         "amlike_xform_apply": (ctypes.c_int, [c_void_p, fp, c_int32, c_int32, fp, c_int32, c_int32, fp, c_int32]),
         "amlike_xform_apply_dev": (ctypes.c_int, [c_void_p, c_void_p, c_int32, ip, c_int32, c_void_p, c_int32, c_int32, ip, c_void_p, c_int32, c_void_p]),
         "amlike_gmm_score_raw": (ctypes.c_int, [c_void_p, c_void_p, fp, c_int32, c_int32, fp, c_int32, c_int32, c_float, fp, c_int32]),

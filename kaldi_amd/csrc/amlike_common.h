@@ -18,13 +18,21 @@ namespace amlike {
 void SetError(const char *fmt, ...);
 const char *LastError();
 
-// The device every handle of this process is bound to (amlike_init).
-int CurrentDevice();
-int NumComputeUnits();
-// Makes the process's device (amlike_init) current on the calling thread: HIP's current device
-// is per thread and starts at 0, so a thread other than the one that called amlike_init would
-// otherwise work on the wrong GPU.  No-op before amlike_init.
-int BindThread();
+// Devices.  amlike_init(d) may be called for several devices (from one thread or from one
+// thread per device).  A handle lives on the device that was current for its creating thread:
+// the device of that thread's latest amlike_init, else of the process's latest.  Every entry
+// point that takes a handle makes the handle's device current on the calling thread first
+// (HIP's current device is per thread and starts at 0), so handles of different devices can
+// be driven from any threads.
+int CurrentDevice();     // the calling thread's device as described above, -1 before any amlike_init
+int NumComputeUnits();   // of the device current in HIP on the calling thread
+int BindDevice(int device);  // makes `device` current in HIP (no-op for -1)
+int BindThread();            // BindDevice(CurrentDevice())
+// BindDevice(the handle's device), or BindThread() for a null handle (the caller reports it)
+template <typename H>
+int BindHandle(const H *h) {
+  return h ? BindDevice(h->device) : BindThread();
+}
 // Looks up, once per device, the address of the built-in scratch array of the entry point that
 // allocates nothing (gmm_score.hip); called by amlike_init with `device` current.
 int SetupNoAllocScratch(int device);

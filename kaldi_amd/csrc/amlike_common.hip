@@ -2,6 +2,7 @@
 #include "amlike_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -12,8 +13,10 @@
 namespace amlike {
 
 static thread_local char g_err[512] = "";
-static int g_device = -1;
-static int g_num_cu = 0;
+constexpr int kMaxDevices = 64;
+static std::atomic<int> g_default_device{-1};   // the device of the latest amlike_init of the process
+static thread_local int t_device = -1;          // the device of the calling thread's latest amlike_init
+static int g_num_cu[kMaxDevices] = {0};
 
 void SetError(const char *fmt, ...) {
   va_list ap;
@@ -23,16 +26,22 @@ void SetError(const char *fmt, ...) {
 }
 
 const char *LastError() { return g_err; }
-int CurrentDevice() { return g_device; }
-int NumComputeUnits() { return g_num_cu; }
+int CurrentDevice() { return t_device >= 0 ? t_device : g_default_device.load(); }
+int NumComputeUnits() {
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur < 0 || cur >= kMaxDevices) return 0;
+  return g_num_cu[cur];
+}
 
-int BindThread() {
-  if (g_device < 0) return AMLIKE_OK;
+int BindDevice(int device) {
+  if (device < 0) return AMLIKE_OK;
   int cur = -1;
   AMLIKE_HIP(hipGetDevice(&cur));
-  if (cur != g_device) AMLIKE_HIP(hipSetDevice(g_device));
+  if (cur != device) AMLIKE_HIP(hipSetDevice(device));
   return AMLIKE_OK;
 }
+
+int BindThread() { return BindDevice(CurrentDevice()); }
 
 int DeviceBuffer::Reserve(size_t want) {
   if (want <= bytes) return AMLIKE_OK;
@@ -140,12 +149,12 @@ class HostCopyPool {
 constexpr size_t kStageBytes = (size_t)32 << 20;
 constexpr int kStageBuffers = 3;
 struct Staging {
-  std::mutex mu;  // one pipelined copy at a time per process
+  std::mutex mu;  // one pipelined copy at a time per device
   char *buf[kStageBuffers] = {nullptr, nullptr, nullptr};
   hipEvent_t ev[kStageBuffers] = {nullptr, nullptr, nullptr};
-  int device = -1;
+  bool ready = false;
 };
-Staging g_staging;
+Staging g_staging_tab[kMaxDevices];
 
 bool IsPageLocked(const void *p) {
   hipPointerAttribute_t attr;
@@ -170,13 +179,16 @@ int CopyMatrixToHost(float *out, size_t ldo, const float *d_src, int rows, int c
     AMLIKE_HIP(hipStreamSynchronize(st));
     return AMLIKE_OK;
   }
+  int dev = 0;
+  AMLIKE_HIP(hipGetDevice(&dev));  // the handle's device (bound by the caller)
+  Staging &g_staging = g_staging_tab[std::max(0, std::min(dev, kMaxDevices - 1))];
   std::lock_guard<std::mutex> lock(g_staging.mu);
-  if (g_staging.device != g_device) {  // first use (one device per process)
+  if (!g_staging.ready) {  // first use on this device
     for (int i = 0; i < kStageBuffers; ++i) {
       AMLIKE_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_staging.buf[i]), kStageBytes, hipHostMallocDefault));
       AMLIKE_HIP(hipEventCreateWithFlags(&g_staging.ev[i], hipEventDisableTiming));
     }
-    g_staging.device = g_device;
+    g_staging.ready = true;
   }
   const int chunk_rows = (int)std::max<size_t>(1, kStageBytes / row_bytes);
   const int nchunks = (rows + chunk_rows - 1) / chunk_rows;
@@ -241,7 +253,7 @@ int amlike_device_count(void) {
 
 int amlike_init(int device) {
   int n = amlike_device_count();
-  if (n <= 0 || device < 0 || device >= n) {
+  if (n <= 0 || device < 0 || device >= n || device >= amlike::kMaxDevices) {
     amlike::SetError("amlike_init: device %d not available (%d visible)", device, n);
     return AMLIKE_ENODEV;
   }
@@ -254,8 +266,9 @@ int amlike_init(int device) {
     return AMLIKE_ENODEV;
   }
   if (int rc = amlike::SetupNoAllocScratch(device)) return rc;
-  amlike::g_device = device;
-  amlike::g_num_cu = prop.multiProcessorCount;
+  amlike::g_num_cu[device] = prop.multiProcessorCount;
+  amlike::t_device = device;
+  amlike::g_default_device.store(device);
   return AMLIKE_OK;
 }
 

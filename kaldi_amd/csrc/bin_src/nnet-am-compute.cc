@@ -1,14 +1,19 @@
 // nnet-am-compute on MI355X: same command line, inputs and outputs as the reference
 // binary (/root/reference/src/nnet2bin/nnet-am-compute.cc:27-110); NnetComputation()
-// (:91) and the optional floor + log (:93-96) run on the GPU through libamlike.
+// (:91) and the optional floor + log (:93-96) run on the GPU through libamlike.  Extra
+// options: --device, --num-gpus (one worker thread and one copy of the net per GPU, two
+// utterances in flight on each, outputs still in input order).
 #include <chrono>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "../host/kaldi_io.h"
 #include "../host/nnet_model.h"
+#include "../host/ordered_scorer.h"
 #include "../host/parse_options.h"
-#include "../host/pipeline.h"
 
 int main(int argc, char *argv[]) {
   using namespace kaldi_amd;
@@ -23,7 +28,8 @@ int main(int argc, char *argv[]) {
         "Usage:  nnet-am-compute [options] <model-in> <feature-rspecifier> "
         "<feature-or-loglikes-wspecifier>\n";
     bool apply_log = false, pad_input = true, divide_by_priors = false;
-    int32 device = 0;
+    int32 device = 0, num_gpus = 1;
+    std::string device_list;
     float prob_scale = 1.0f;
     ParseOptions po(usage);
     po.Register("apply-log", &apply_log, "Apply a log to the result of the computation before outputting.");
@@ -34,13 +40,18 @@ int main(int argc, char *argv[]) {
                 "Output pseudo log-likelihoods log(p) - log(prior), scaled by --prob-scale "
                 "(what DecodableAmNnet computes); implies --apply-log.");
     po.Register("prob-scale", &prob_scale, "Scale applied with --divide-by-priors");
-    po.Register("device", &device, "GPU to use");
+    po.Register("device", &device, "GPU to use (the first one with --num-gpus)");
+    po.Register("num-gpus", &num_gpus, "Number of GPUs: devices --device .. --device + num-gpus - 1");
+    po.Register("devices", &device_list,
+                "Comma-separated device of each worker, instead of --device/--num-gpus (a device may "
+                "repeat: several workers on one GPU)");
     po.Read(argc, argv);
     if (po.NumArgs() != 3) {
       po.PrintUsage();
       return 1;
     }
-    CheckAmlike(amlike_init(device));
+    const std::vector<int32> devices = ParseDeviceList(device_list, num_gpus, device);
+    CheckAmlike(amlike_init(devices[0]));
     TransitionModel trans_model;
     AmNnet am_nnet;
     {
@@ -50,42 +61,85 @@ int main(int argc, char *argv[]) {
       am_nnet.Read(ki.Stream(), binary);
     }
     const Nnet &nnet = am_nnet.GetNnet();
-    long long num_done = 0, num_frames = 0;
+    const int32 context = nnet.LeftContext() + nnet.RightContext();
+    long long num_done = 0, num_err = 0, num_frames = 0;
     SequentialMatrixReader feature_reader(po.GetArg(2));
     MatrixWriter writer(po.GetArg(3));
     const int mode = divide_by_priors ? AMLIKE_NNET_LOGLIKES : apply_log ? AMLIKE_NNET_LOG : AMLIKE_NNET_POSTERIORS;
-    // Two utterances in flight: reading utterance k+1 and writing utterance k-1 overlap the
-    // GPU's work on utterance k.
-    am_nnet.Engine();  // weight images built and uploaded before the clock starts
+    // every worker builds the weight images and uploads them to its device, before the clock starts
+    struct NnetDeleter {
+      void operator()(amlike_nnet_t *n) const { amlike_nnet_destroy(n); }
+    };
+    std::vector<std::unique_ptr<amlike_nnet_t, NnetDeleter>> engines(devices.size());
+    std::mutex engines_mu;
+    size_t engines_made = 0;
+    // (declared before the scorer: its workers hold pointers to these jobs until it is gone)
+    std::vector<std::unique_ptr<ScoreJob>> window, previous;
+    OrderedScorer scorer(devices, [&]() {
+      amlike_nnet_t *h = am_nnet.CreateEngine();
+      {
+        std::lock_guard<std::mutex> lock(engines_mu);
+        engines[engines_made++].reset(h);
+      }
+      return std::unique_ptr<LikelihoodPipeline>(new LikelihoodPipeline(h, context, pad_input, mode, prob_scale));
+    });
     const auto t0 = std::chrono::steady_clock::now();
-    LikelihoodPipeline pipe(am_nnet, pad_input, mode, prob_scale);
-    auto drain_one = [&]() {
-      std::string utt;
-      const PinnedMatrix &output = pipe.Front(&utt);
-      writer.Write(utt, output.Data(), output.NumRows(), output.NumCols(), output.Stride());
-      pipe.Pop();
-      num_done++;
+    std::vector<long long> worker_frames(devices.size(), 0);
+    // One job per utterance.  Window k is handed to the GPUs, then window k - 1 is written
+    // while they work on it.
+    auto commit = [&](std::vector<std::unique_ptr<ScoreJob>> *jobs) {
+      for (auto &j : *jobs) {
+        scorer.WaitFor(j.get());
+        if (j->errors[0].empty()) {
+          writer.Write(j->keys[0], j->out.Data(), j->out.NumRows(), j->out.NumCols(), j->out.Stride());
+          num_done++;
+          worker_frames[j->worker] += j->rows[0];
+        } else {
+          std::cerr << "WARNING (nnet-am-compute) utterance " << j->keys[0] << " failed: " << j->errors[0] << '\n';
+          num_err++;
+        }
+      }
+      jobs->clear();
+    };
+    auto turn = [&]() {
+      std::vector<ScoreJob *> jobs;
+      for (auto &j : window) jobs.push_back(j.get());
+      scorer.Publish(jobs);
+      commit(&previous);
+      previous.swap(window);
     };
     for (; !feature_reader.Done(); feature_reader.Next()) {
       const std::string utt = feature_reader.Key();
       const Matrix &feats = feature_reader.Value();
       int32 output_frames = feats.NumRows();
-      if (!pad_input) output_frames -= nnet.LeftContext() + nnet.RightContext();
+      if (!pad_input) output_frames -= context;
       if (output_frames <= 0) {
         std::cerr << "WARNING (nnet-am-compute) Skipping utterance " << utt
                   << " because output would be empty.\n";
         continue;
       }
-      if (pipe.Full()) drain_one();
-      pipe.Submit(utt, feats);
+      if (feats.NumCols() != nnet.InputDim())  // fatal, as in the reference (nnet2/nnet-compute.cc:45-48)
+        KALDI_AMD_ERR("Dim mismatch: data dim = " << feats.NumCols() << " vs. model dim = " << nnet.InputDim());
+      std::unique_ptr<ScoreJob> job(new ScoreJob);
+      job->keys.push_back(utt);
+      job->rows.push_back(feats.NumRows());
+      job->feats = feats;
       num_frames += feats.NumRows();
+      window.push_back(std::move(job));
+      if (static_cast<int32>(window.size()) >= scorer.WindowSize()) turn();
     }
-    while (!pipe.Empty()) drain_one();
+    turn();
+    commit(&previous);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::cerr << "LOG (nnet-am-compute) " << num_frames << " frames in " << secs << " s ("
               << (secs > 0 ? num_frames / secs : 0.0) << " frames/s including file I/O)\n";
+    if (devices.size() > 1)
+      for (size_t w = 0; w < devices.size(); ++w)
+        std::cerr << "LOG (nnet-am-compute) worker " << w << " on GPU " << devices[w] << ": " << worker_frames[w]
+                  << " frames\n";
     std::cerr << "LOG (nnet-am-compute) Processed " << num_done << " feature files, " << num_frames
-              << " frames of input were processed.\n";
+              << " frames of input were processed." << (num_err ? " Failed: " + std::to_string(num_err) : std::string())
+              << "\n";
     return (num_done == 0 ? 1 : 0);
   } catch (const std::exception &e) {
     std::cerr << e.what() << '\n';

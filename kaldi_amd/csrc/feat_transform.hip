@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void feat_splice_affine_kernel(
 using namespace amlike;
 
 struct amlike_xform {
+  int device = 0;
   int dim = 0, left = 0, right = 0, rows = 0, cols = 0;
   float *d_mat = nullptr;
   hipStream_t stream = nullptr;
@@ -113,6 +114,7 @@ int amlike_xform_create(int32_t dim, int32_t left, int32_t right, const float *m
     if (rc != AMLIKE_OK) return rc;
   }
   amlike_xform *x = new amlike_xform;
+  x->device = CurrentDevice();
   x->dim = dim;
   x->left = left;
   x->right = right;
@@ -135,7 +137,7 @@ int amlike_xform_create(int32_t dim, int32_t left, int32_t right, const float *m
 }
 
 int amlike_xform_destroy(amlike_xform_t *x) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(x)) return brc;
   if (!x) return AMLIKE_OK;
   (void)hipFree(x->d_mat);
   x->ws_off.Free();
@@ -148,6 +150,7 @@ int amlike_xform_destroy(amlike_xform_t *x) {
 }
 
 int32_t amlike_xform_input_dim(const amlike_xform_t *x) { return x ? x->dim : 0; }
+int32_t amlike_xform_device(const amlike_xform_t *x) { return x ? x->device : -1; }
 int32_t amlike_xform_output_dim(const amlike_xform_t *x) {
   if (!x) return 0;
   return x->d_mat ? x->rows : x->dim * (x->left + x->right + 1);
@@ -157,7 +160,7 @@ int amlike_xform_apply_dev(amlike_xform_t *x, const float *d_in, int32_t ld,
                            const int32_t *utt_rows, int32_t num_utts, const float *d_spk_mats,
                            int32_t rows2, int32_t cols2, const int32_t *utt_mat, float *d_out,
                            int32_t ldo, void *stream) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(x)) return brc;
   if (!x || !d_in || !d_out || !utt_rows || num_utts <= 0 || ld < x->dim) {
     SetError("amlike_xform_apply: invalid argument");
     return AMLIKE_EINVAL;
@@ -220,7 +223,7 @@ int amlike_xform_apply_dev(amlike_xform_t *x, const float *d_in, int32_t ld,
 
 int amlike_xform_apply(amlike_xform_t *x, const float *feats, int32_t T, int32_t ld,
                        const float *spk_mat, int32_t rows2, int32_t cols2, float *out, int32_t ldo) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(x)) return brc;
   if (!x || !feats || !out || T <= 0 || ld < x->dim) {
     SetError(T <= 0 ? "SpliceFrames: empty input" : "amlike_xform_apply: invalid argument");
     return AMLIKE_EINVAL;

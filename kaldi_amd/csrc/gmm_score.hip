@@ -2440,7 +2440,7 @@ int amlike_gmm_create(const float *gconsts, const float *means_invvars, const fl
 }
 
 int amlike_gmm_destroy(amlike_gmm_t *g) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   if (!g) return AMLIKE_OK;
   (void)hipFree(g->d_apack);
   (void)hipFree(g->d_apack_safe);
@@ -2475,12 +2475,13 @@ int amlike_gmm_destroy(amlike_gmm_t *g) {
 int32_t amlike_gmm_num_pdfs(const amlike_gmm_t *g) { return g ? g->num_pdfs : 0; }
 int32_t amlike_gmm_num_gauss(const amlike_gmm_t *g) { return g ? g->num_gauss : 0; }
 int32_t amlike_gmm_dim(const amlike_gmm_t *g) { return g ? g->dim : 0; }
+int32_t amlike_gmm_device(const amlike_gmm_t *g) { return g ? g->device : -1; }
 const char *amlike_gmm_kernel_info(const amlike_gmm_t *g) { return g ? g->info.c_str() : ""; }
 
 int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32_t ld,
                          int32_t feat_dim, float log_sum_exp_prune, float *d_out, int32_t ldo,
                          void *stream) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   int rc = CheckScoreArgs(g, T, ld, feat_dim, ldo, d_feats, d_out);
   if (rc != AMLIKE_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2527,7 +2528,7 @@ int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32
 
 int amlike_gmm_score_dev_noalloc(amlike_gmm_t *g, const float *d_feats, int32_t T, int32_t ld,
                                  int32_t feat_dim, float *d_out, int32_t ldo, void *stream) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   int rc = CheckScoreArgs(g, T, ld, feat_dim, ldo, d_feats, d_out);
   if (rc != AMLIKE_OK) return rc;
   if (!g->variant || g->variant->mode == 0) {
@@ -2548,7 +2549,7 @@ int amlike_gmm_score_dev_noalloc(amlike_gmm_t *g, const float *d_feats, int32_t 
 size_t amlike_gmm_noalloc_scratch_bytes(void) { return kNoAllocScratchBytes; }
 
 int amlike_gmm_poll(amlike_gmm_t *g, void *stream) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   if (!g) return AMLIKE_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int flag = 0;
@@ -2588,7 +2589,7 @@ static int ScoreResidentToHost(amlike_gmm *g, const float *df, int T, int dld, f
 
 int amlike_gmm_score(amlike_gmm_t *g, const float *feats, int32_t T, int32_t ld,
                      int32_t feat_dim, float log_sum_exp_prune, float *out, int32_t ldo) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   int rc = CheckScoreArgs(g, T, ld, feat_dim, ldo, feats, out);
   if (rc != AMLIKE_OK) return rc;
   std::lock_guard<std::mutex> lock(g->mu);
@@ -2615,9 +2616,14 @@ int amlike_gmm_score(amlike_gmm_t *g, const float *feats, int32_t T, int32_t ld,
 int amlike_gmm_score_raw(amlike_gmm_t *g, amlike_xform_t *xf, const float *raw, int32_t T, int32_t ld,
                          const float *spk_mat, int32_t rows2, int32_t cols2,
                          float log_sum_exp_prune, float *out, int32_t ldo) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   if (!g || !xf || !raw || !out || T <= 0 || ld < amlike_xform_input_dim(xf) || ldo < g->num_pdfs) {
     SetError(T <= 0 && g && xf && raw && out ? "SpliceFrames: empty input" : "amlike_gmm_score_raw: invalid argument");
+    return AMLIKE_EINVAL;
+  }
+  if (amlike_xform_device(xf) != g->device) {
+    SetError("amlike_gmm_score_raw: the transform lives on device %d, the model on device %d",
+             amlike_xform_device(xf), g->device);
     return AMLIKE_EINVAL;
   }
   const int final_dim = spk_mat ? rows2 : amlike_xform_output_dim(xf);
@@ -2650,7 +2656,7 @@ int amlike_gmm_score_raw(amlike_gmm_t *g, amlike_xform_t *xf, const float *raw, 
 int amlike_gmm_score_submit(amlike_gmm_t *g, const float *feats, int32_t T, int32_t ld,
                             int32_t feat_dim, float log_sum_exp_prune, float *out, int32_t ldo,
                             int32_t *ticket) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   int rc = CheckScoreArgs(g, T, ld, feat_dim, ldo, feats, out);
   if (rc != AMLIKE_OK) return rc;
   const int P = g->num_pdfs;
@@ -2703,7 +2709,7 @@ int amlike_gmm_score_submit(amlike_gmm_t *g, const float *feats, int32_t T, int3
 }
 
 int amlike_gmm_score_wait(amlike_gmm_t *g, int32_t ticket) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   if (!g || ticket < 0) {
     SetError("amlike_gmm_score_wait: invalid argument");
     return AMLIKE_EINVAL;
@@ -2734,7 +2740,7 @@ int amlike_gmm_score_wait(amlike_gmm_t *g, int32_t ticket) {
 int amlike_gmm_gauss_loglikes_dev(amlike_gmm_t *g, int32_t pdf_begin, int32_t pdf_end,
                                   const float *d_feats, int32_t T, int32_t ld, int32_t feat_dim,
                                   float *d_out, int32_t ldo, void *stream) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   if (!g || !d_feats || !d_out || pdf_begin < 0 || pdf_end > g->num_pdfs || pdf_begin >= pdf_end) {
     SetError("amlike_gmm_gauss_loglikes: invalid argument");
     return AMLIKE_EINVAL;
@@ -2759,7 +2765,7 @@ int amlike_gmm_gauss_loglikes_dev(amlike_gmm_t *g, int32_t pdf_begin, int32_t pd
 int amlike_gmm_gauss_loglikes(amlike_gmm_t *g, int32_t pdf_begin, int32_t pdf_end,
                               const float *feats, int32_t T, int32_t ld, int32_t feat_dim,
                               float *out, int32_t ldo) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   if (!g || !feats || !out || pdf_begin < 0 || pdf_end > g->num_pdfs || pdf_begin >= pdf_end) {
     SetError("amlike_gmm_gauss_loglikes: invalid argument");
     return AMLIKE_EINVAL;
@@ -2802,7 +2808,7 @@ int amlike_gmm_gauss_loglikes(amlike_gmm_t *g, int32_t pdf_begin, int32_t pdf_en
 
 int amlike_gmm_gselect(amlike_gmm_t *g, int32_t pdf, const float *feats, int32_t T, int32_t ld,
                        int32_t feat_dim, int32_t num_gselect, int32_t *out_idx, double *tot_loglike) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   if (!g || !feats || !out_idx || pdf < 0 || pdf >= g->num_pdfs || num_gselect <= 0 || T <= 0 ||
       ld < feat_dim) {
     SetError("amlike_gmm_gselect: invalid argument");
@@ -2859,7 +2865,7 @@ int amlike_gmm_gselect(amlike_gmm_t *g, int32_t pdf, const float *feats, int32_t
 }
 
 int amlike_gmm_profile_kernel(amlike_gmm_t *g, int32_t enable) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   if (!g) return AMLIKE_EINVAL;
   std::lock_guard<std::mutex> lock(g->lane_mu);
   if (enable && g->kev.empty()) {
@@ -2876,7 +2882,7 @@ int amlike_gmm_profile_kernel(amlike_gmm_t *g, int32_t enable) {
 }
 
 int amlike_gmm_kernel_time(amlike_gmm_t *g, float *mean_ms, int32_t *launches) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   if (!g || !mean_ms) return AMLIKE_EINVAL;
   std::lock_guard<std::mutex> lock(g->lane_mu);
   double sum = 0.0;
@@ -2895,7 +2901,7 @@ int amlike_gmm_kernel_time(amlike_gmm_t *g, float *mean_ms, int32_t *launches) {
 int amlike_gmm_time_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32_t ld,
                               int32_t feat_dim, float *d_out, int32_t ldo, void *stream,
                               int32_t iters, float *ms_per_launch) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(g)) return brc;
   if (!ms_per_launch || iters <= 0) return AMLIKE_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipEvent_t e0, e1;

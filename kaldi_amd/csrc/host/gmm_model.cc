@@ -330,7 +330,12 @@ int32 AmDiagGmm::NumGauss() const {
 }
 
 amlike_gmm_t *AmDiagGmm::Engine() const {
-  if (!engine_) {
+  if (!engine_) engine_.reset(CreateEngine());
+  return engine_.get();
+}
+
+amlike_gmm_t *AmDiagGmm::CreateEngine() const {
+  {
     const int32 P = NumPdfs(), D = Dim(), G = NumGauss();
     if (P == 0) KaldiErr("AmDiagGmm: empty model");
     std::vector<float> gc(G), miv(static_cast<size_t>(G) * D), iv(static_cast<size_t>(G) * D);
@@ -349,9 +354,8 @@ amlike_gmm_t *AmDiagGmm::Engine() const {
     }
     amlike_gmm_t *g = nullptr;
     CheckAmlike(amlike_gmm_create(gc.data(), miv.data(), iv.data(), offs.data(), P, G, D, &g));
-    engine_.reset(g);
+    return g;
   }
-  return engine_.get();
 }
 
 void AmDiagGmm::LogLikelihoods(const Matrix &feats, Matrix *loglikes, BaseFloat prune) const {

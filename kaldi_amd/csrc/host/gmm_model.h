@@ -113,6 +113,8 @@ class AmDiagGmm {
   void LogLikelihoods(const Matrix &feats, Matrix *loglikes, BaseFloat log_sum_exp_prune = -1.0) const;
 
   amlike_gmm_t *Engine() const;  // the packed device copy (created on first use)
+  // A further device copy on the calling thread's device (amlike_init); the caller destroys it.
+  amlike_gmm_t *CreateEngine() const;
 
  private:
   std::vector<DiagGmm> densities_;

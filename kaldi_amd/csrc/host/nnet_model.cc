@@ -203,7 +203,12 @@ void AmNnet::Read(std::istream &is, bool binary) {  // nnet2/am-nnet.cc:39-42
 }
 
 amlike_nnet_t *AmNnet::Engine() const {
-  if (!engine_) {
+  if (!engine_) engine_.reset(CreateEngine());
+  return engine_.get();
+}
+
+amlike_nnet_t *AmNnet::CreateEngine() const {
+  {
     const int32 n = nnet_.NumComponents();
     std::vector<amlike_component_t> comps(n);
     std::vector<std::vector<float>> dense(n);
@@ -233,9 +238,8 @@ amlike_nnet_t *AmNnet::Engine() const {
     }
     amlike_nnet_t *h = nullptr;
     CheckAmlike(amlike_nnet_create(comps.data(), n, priors_.Dim() ? priors_.Data() : nullptr, priors_.Dim(), &h));
-    engine_.reset(h);
+    return h;
   }
-  return engine_.get();
 }
 
 void NnetComputation(const AmNnet &am, const Matrix &feats, bool pad_input, int mode,

@@ -53,6 +53,8 @@ class AmNnet {
   const Vector &Priors() const { return priors_; }
   int32 NumPdfs() const { return nnet_.OutputDim(); }
   amlike_nnet_t *Engine() const;  // device-resident pipeline, created on first use
+  // A further one on the calling thread's device (amlike_init); the caller destroys it.
+  amlike_nnet_t *CreateEngine() const;
 
  private:
   Nnet nnet_;

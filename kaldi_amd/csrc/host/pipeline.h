@@ -70,10 +70,26 @@ class LikelihoodPipeline {
   explicit LikelihoodPipeline(const AmDiagGmm &am, BaseFloat log_sum_exp_prune = -1.0);
   // nnet2 output in one of the AMLIKE_NNET_* modes (AMLIKE_NNET_LOGLIKES = DecodableAmNnet).
   LikelihoodPipeline(const nnet2::AmNnet &am, bool pad_input, int mode, BaseFloat prob_scale);
+  // The same over handles the caller owns (one per device in the multi-GPU drivers); context =
+  // the net's left + right context.
+  LikelihoodPipeline(amlike_gmm_t *gmm, BaseFloat log_sum_exp_prune);
+  LikelihoodPipeline(amlike_nnet_t *nnet, int32 context, bool pad_input, int mode, BaseFloat prob_scale);
   ~LikelihoodPipeline();
   bool Full() const { return count_ == 2; }
   bool Empty() const { return count_ == 0; }
   void Submit(const std::string &key, const Matrix &feats);
+  // Rows given by pointer; the result goes to `out` (page-locked memory for full speed, at
+  // least OutputRows(rows) x NumPdfs, row stride out_stride) instead of the slot's own matrix.
+  void SubmitInto(const std::string &key, const float *feats, int32 rows, int32 stride, float *out,
+                  int32 out_stride);
+  int32 OutputRows(int32 input_rows) const { return input_rows - ctx_; }
+  // Is row t of the result a function of row t of the input alone (so that utterances may be
+  // stacked into one submission)?  True for a GMM, false for a net (temporal context, padding).
+  bool RowsIndependent() const { return gmm_ != nullptr; }
+  int32 NumPdfs() const { return num_pdfs_; }
+  int32 Dim() const { return dim_; }
+  // Waits for the oldest submission (as Front does) without handing out its matrix.
+  void WaitFront(std::string *key);
   // The oldest submission, waited for; valid until Pop().  Throws what the synchronous call
   // would have thrown ("Invalid answer ...").
   const PinnedMatrix &Front(std::string *key);
@@ -82,6 +98,7 @@ class LikelihoodPipeline {
  private:
   struct Slot {
     PinnedMatrix in, out;
+    bool external_out = false;
     std::string key;
     int32 ticket = -1;
     bool waited = false;

@@ -1641,6 +1641,7 @@ struct Stage {
 using namespace amlike;
 
 struct amlike_nnet {
+  int device = 0;
   std::vector<Stage> stages;  // after fusion
   int input_dim = 0, output_dim = 0, left = 0, right = 0;
   int num_priors = 0;
@@ -2287,6 +2288,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
     if (rc != AMLIKE_OK) return rc;
   }
   amlike_nnet *n = new amlike_nnet;
+  n->device = CurrentDevice();
   if (const char *e = getenv("AMLIKE_NNET_GEMM")) {
     n->gemm_f32 = strcmp(e, "f32") == 0;
     n->gemm_inline_split = strcmp(e, "inline") == 0;
@@ -2507,11 +2509,12 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
 }
 
 int amlike_nnet_destroy(amlike_nnet_t *n) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(n)) return brc;
   if (n) FreeNnet(n);
   return AMLIKE_OK;
 }
 int32_t amlike_nnet_input_dim(const amlike_nnet_t *n) { return n ? n->input_dim : 0; }
+int32_t amlike_nnet_device(const amlike_nnet_t *n) { return n ? n->device : -1; }
 int32_t amlike_nnet_output_dim(const amlike_nnet_t *n) { return n ? n->output_dim : 0; }
 int32_t amlike_nnet_left_context(const amlike_nnet_t *n) { return n ? n->left : 0; }
 int32_t amlike_nnet_right_context(const amlike_nnet_t *n) { return n ? n->right : 0; }
@@ -2520,7 +2523,7 @@ int amlike_nnet_compute_batch_dev(amlike_nnet_t *n, const float *d_feats, int32_
                                   const int32_t *utt_rows, int32_t num_utts, int32_t pad_input,
                                   int32_t mode, float prob_scale, float *d_out, int32_t ldo,
                                   void *stream, int64_t *total_out_rows) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(n)) return brc;
   if (!n || !d_feats || !d_out || !utt_rows || num_utts <= 0 || ld < n->input_dim ||
       ldo < n->output_dim || mode < 0 || mode > 2) {
     SetError("amlike_nnet_compute: invalid argument");
@@ -2533,14 +2536,14 @@ int amlike_nnet_compute_batch_dev(amlike_nnet_t *n, const float *d_feats, int32_
 int amlike_nnet_compute_dev(amlike_nnet_t *n, const float *d_feats, int32_t T, int32_t ld,
                             int32_t pad_input, int32_t mode, float prob_scale, float *d_out,
                             int32_t ldo, void *stream) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(n)) return brc;
   return amlike_nnet_compute_batch_dev(n, d_feats, ld, &T, 1, pad_input, mode, prob_scale, d_out,
                                        ldo, stream, nullptr);
 }
 
 int amlike_nnet_compute(amlike_nnet_t *n, const float *feats, int32_t T, int32_t ld,
                         int32_t pad_input, int32_t mode, float prob_scale, float *out, int32_t ldo) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(n)) return brc;
   if (!n || !feats || !out || T <= 0 || ld < n->input_dim || ldo < n->output_dim) {
     SetError("amlike_nnet_compute: invalid argument");
     return AMLIKE_EINVAL;
@@ -2576,7 +2579,7 @@ int amlike_nnet_compute(amlike_nnet_t *n, const float *feats, int32_t T, int32_t
 int amlike_nnet_compute_submit(amlike_nnet_t *n, const float *feats, int32_t T, int32_t ld,
                                int32_t pad_input, int32_t mode, float prob_scale, float *out,
                                int32_t ldo, int32_t *ticket) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(n)) return brc;
   if (!n || !feats || !out || !ticket || T <= 0 || ld < n->input_dim || ldo < n->output_dim) {
     SetError("amlike_nnet_compute_submit: invalid argument");
     return AMLIKE_EINVAL;
@@ -2641,7 +2644,7 @@ int amlike_nnet_compute_submit(amlike_nnet_t *n, const float *feats, int32_t T, 
 }
 
 int amlike_nnet_compute_wait(amlike_nnet_t *n, int32_t ticket) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(n)) return brc;
   if (!n || ticket < 0) {
     SetError("amlike_nnet_compute_wait: invalid argument");
     return AMLIKE_EINVAL;
@@ -2665,7 +2668,7 @@ int amlike_nnet_compute_wait(amlike_nnet_t *n, int32_t ticket) {
 int amlike_nnet_time_compute_dev(amlike_nnet_t *n, const float *d_feats, int32_t T, int32_t ld,
                                  int32_t pad_input, int32_t mode, float prob_scale, float *d_out,
                                  int32_t ldo, void *stream, int32_t iters, float *ms_per_pass) {
-  if (int brc = BindThread()) return brc;
+  if (int brc = BindHandle(n)) return brc;
   if (!ms_per_pass || iters <= 0) return AMLIKE_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipEvent_t e0, e1;

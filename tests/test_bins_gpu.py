@@ -96,6 +96,75 @@ def test_gmm_compute_likes_yesno_shape(tmp_path):
     assert (have.argmax(1) == want.argmax(1)).mean() >= 0.9999
 
 
+@pytest.fixture(scope="module")
+def many_utts(tmp_path_factory):
+    """40 utterances of mixed length, one of them without frames."""
+    d = tmp_path_factory.mktemp("many")
+    model = synth.make_gmm(39, 120, 900, seed=21)
+    write_gmm_mdl(str(d / "final.mdl"), model)
+    rng = np.random.default_rng(7)
+    lens = [int(n) for n in rng.integers(20, 700, size=40)]
+    lens[11] = 0
+    items = [("spk%d-utt%03d" % (i % 3, i), synth.make_feats(model, n, seed=500 + i) if n else
+              np.zeros((0, 39), np.float32)) for i, n in enumerate(lens)]
+    kio.write_ark(str(d / "feats.ark"), items)
+    return d, model, items
+
+
+def test_gmm_compute_likes_several_workers_same_archive(many_utts):
+    """One worker thread and handle per device (--num-gpus); several workers sharing the only GPU of
+    the test box (--devices=0,0,0) must write the archive a single worker writes, byte for byte:
+    the jobs are cut the same way, scored by whoever is free, the longest of a window first, and
+    committed in input order (the contract of the reference's TaskSequencer,
+    thread/kaldi-task-sequence.h:78-129).  An utterance without frames comes out as a matrix of
+    no rows, in its place."""
+    d, model, items = many_utts
+    outs = []
+    for tag, opts in [("one", []), ("three", ["--devices=0,0,0"]), ("two", ["--devices=0,0", "--frames-per-batch=1"])]:
+        out = str(d / ("likes_%s.ark" % tag))
+        fpb = [] if any(o.startswith("--frames-per-batch") for o in opts) else ["--frames-per-batch=900"]
+        p = run("gmm-compute-likes", *opts, *fpb, str(d / "final.mdl"), "ark:" + str(d / "feats.ark"), "ark:" + out)
+        assert b"computed likelihoods for 40 utterances" in p.stderr
+        outs.append(open(out, "rb").read())
+        if tag == "three":
+            assert p.stderr.count(b"worker ") == 3
+    assert outs[0] == outs[1] == outs[2]
+    got = kio.read_ark(str(d / "likes_three.ark"))
+    assert [k for k, _ in got] == [k for k, _ in items]
+    assert got[11][1].shape == (0, 120)
+    for (_, f), (_, l) in zip(items, got):
+        if f.shape[0]:
+            assert np.abs(l - oracle_gmm(model, f)).max() <= TOL
+
+
+def test_gmm_compute_likes_a_bad_utterance_costs_only_itself(many_utts, tmp_path):
+    """Non-finite features in one utterance of a batch: its batch-mates are scored again on their
+    own and written, the bad one is reported and counted, the run goes on (the reference's drivers
+    count an utterance that fails and continue, gmmbin/gmm-latgen-faster.cc:118-122)."""
+    d, model, items = many_utts
+    bad = [(k, f.copy()) for k, f in items[:12] if f.shape[0]]
+    bad[4][1][3, 5] = np.nan
+    kio.write_ark(str(tmp_path / "feats.ark"), bad)
+    out = str(tmp_path / "likes.ark")
+    p = run("gmm-compute-likes", "--devices=0,0", "--frames-per-batch=1500", str(d / "final.mdl"),
+            "ark:" + str(tmp_path / "feats.ark"), "ark:" + out)
+    warning = [l for l in p.stderr.split(b"\n") if b"utterance " + bad[4][0].encode() + b" failed:" in l]
+    assert len(warning) == 1 and b"Invalid answer" in warning[0], p.stderr
+    assert b"computed likelihoods for %d utterances, failed for 1" % (len(bad) - 1) in p.stderr
+    got = kio.read_ark(out)
+    assert [k for k, _ in got] == [k for i, (k, _) in enumerate(bad) if i != 4]
+    for k, l in got:
+        f = dict(bad)[k]
+        assert np.abs(l - oracle_gmm(model, f)).max() <= TOL
+
+
+def test_num_gpus_beyond_the_visible_devices_is_refused(many_utts, tmp_path):
+    d, _, _ = many_utts
+    p = run("gmm-compute-likes", "--num-gpus=64", str(d / "final.mdl"), "ark:" + str(d / "feats.ark"),
+            "ark:" + str(tmp_path / "x.ark"), ok=False)
+    assert p.returncode != 0 and b"visible" in p.stderr
+
+
 def test_gmm_compute_likes_text_model_and_text_output(gmm_files, tmp_path):
     d, model, items, _ = gmm_files
     small = synth.make_gmm(13, 9, 40, seed=22)
@@ -180,6 +249,28 @@ def test_nnet_am_compute_binary(nnet_files, apply_log, pad):
         else:
             assert np.abs(l - want).max() <= 1e-5
             assert (l.argmax(1) == want.argmax(1)).mean() >= 0.9999
+
+
+def test_nnet_am_compute_several_workers_same_archive(nnet_files, tmp_path):
+    """As for gmm-compute-likes: three workers on one GPU write the bytes one worker writes."""
+    d, comps, priors, _, _ = nnet_files
+    rng = np.random.default_rng(43)
+    items = [("utt%02d" % i, rng.standard_normal((int(n), 40)).astype(np.float32))
+             for i, n in enumerate(rng.integers(9, 400, size=25))]
+    kio.write_ark(str(tmp_path / "feats.ark"), items)
+    outs = []
+    for tag, opts in [("one", []), ("three", ["--devices=0,0,0"])]:
+        out = str(tmp_path / ("o_%s.ark" % tag))
+        p = run("nnet-am-compute", "--divide-by-priors=true", "--prob-scale=0.8", *opts, str(d / "final.mdl"),
+                "ark:" + str(tmp_path / "feats.ark"), "ark:" + out)
+        assert b"Processed 25 feature files" in p.stderr
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]
+    got = kio.read_ark(str(tmp_path / "o_three.ark"))
+    assert [k for k, _ in got] == [k for k, _ in items]
+    for (_, f), (_, l) in zip(items[:5], got[:5]):
+        want = oracle.nnet_compute(comps, priors, f, pad_input=True, mode=2, prob_scale=0.8)
+        assert l.shape == want.shape and np.abs(l - want).max() <= TOL
 
 
 def test_decodable_am_nnet(nnet_files):
