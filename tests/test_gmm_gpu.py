@@ -519,6 +519,57 @@ def test_two_threads_on_two_streams_of_one_handle_device_pointers(amlike_device)
                 assert torch.equal(pair[j], want[t][k % len(feats[t])][j]), (t, k, j)
 
 
+@pytest.mark.parametrize("T", [64, 500, 2000])
+def test_repeated_small_calls_replay_a_recorded_graph(amlike_device, T, monkeypatch):
+    """With AMLIKE_GMM_GRAPHS=1 at the creation of the handle (off by default: the replay measured no
+    faster than the plain launches), small device-pointer calls that come again with the same buffers
+    and shape are recorded as a HIP graph on their second appearance and replayed from the third: every call must give the bits
+    of the first, also after the features changed in place, after a larger call on the same stream
+    has moved the working memory, and for a model with a pdf split over several waves."""
+    import torch
+    m = synth.make_gmm(39, 60, 1300, seed=87)
+    big = synth.make_gmm(39, 1, 700, seed=88)
+    mm = {k: np.concatenate([m[k], big[k]]) for k in ("weights", "means_invvars", "inv_vars")}
+    mm["pdf_offsets"] = np.concatenate([m["pdf_offsets"], [m["pdf_offsets"][-1] + 700]]).astype(np.int32)
+    monkeypatch.setenv("AMLIKE_GMM_GRAPHS", "1")
+    am = gmm.AmDiagGmm(mm["weights"], mm["means_invvars"], mm["inv_vars"], mm["pdf_offsets"])
+    P = am.NumPdfs()
+    stream = torch.cuda.Stream()
+    f1 = torch.from_numpy(synth.make_feats(m, T, seed=89)).cuda()
+    f2 = torch.from_numpy(synth.make_feats(m, T, seed=90)).cuda()
+    feats = f1.clone()
+    out = torch.empty((T, P), dtype=torch.float32, device="cuda")
+
+    def call():
+        am.LogLikelihoodsDevice(feats.data_ptr(), T, feats.stride(0), feats.shape[1], out.data_ptr(), P,
+                                stream=stream.cuda_stream)
+        stream.synchronize()
+        return out.clone()
+
+    first = call()
+    gc, _ = oracle.compute_gconsts(mm["weights"], mm["means_invvars"], mm["inv_vars"])
+    want, _ = oracle.gmm_compute_likes(gc, mm["means_invvars"], mm["inv_vars"], mm["pdf_offsets"], f1.cpu().numpy()[:32])
+    assert np.abs(first.cpu().numpy()[:32] - want).max() < 1e-3
+    for _ in range(4):  # recorded on the second call, replayed afterwards
+        assert torch.equal(call(), first)
+    feats.copy_(f2)  # same buffers, new contents
+    second = call()
+    assert not torch.equal(second, first)
+    feats.copy_(f1)
+    assert torch.equal(call(), first)
+    # a larger call on the same stream grows the working memory under the recorded graphs
+    fbig = torch.from_numpy(synth.make_feats(m, 6000, seed=91)).cuda()
+    obig = torch.empty((6000, P), dtype=torch.float32, device="cuda")
+    am.LogLikelihoodsDevice(fbig.data_ptr(), 6000, fbig.stride(0), fbig.shape[1], obig.data_ptr(), P,
+                            stream=stream.cuda_stream)
+    stream.synchronize()
+    for _ in range(3):
+        assert torch.equal(call(), first)
+    feats.copy_(f2)
+    assert torch.equal(call(), second)
+    am.Poll(stream.cuda_stream)
+
+
 def test_pruned_path_beyond_65535_frames_in_one_chunk(amlike_device):
     """A small model with many frames: the pruned log-sum-exp pass covers them in launches the
     grid can hold (one block row per frame)."""
