@@ -1384,7 +1384,7 @@ __global__ void __launch_bounds__(256, 1)
     // loads and stores) does not wait for any of them.
     constexpr int kRequestKs = 0;
     auto step = [&](int seq, f32x16 (&acc_new)[FT], const f32x16 (&acc_old)[FT], auto kind_tag,
-                    int old_n0) __attribute__((always_inline)) {
+                    int old_n0, bool stores_counted = false) __attribute__((always_inline)) {
       constexpr int kKind = decltype(kind_tag)::value;
       lds_hidden_wait(bnext, lpold);
       if constexpr (kKind == 2) {
@@ -1453,7 +1453,10 @@ __global__ void __launch_bounds__(256, 1)
       // tile seq + 2 (requested kLead - 1.5 steps ago) has landed; every wave has finished
       // reading tile seq
       if constexpr (PREC == 1) mfma_result_gap();
-      wait_vector_memory_but<(kLead - 2) * (kMine + 1)>();
+      // (stores_counted: this step and the kLead - 2 before it each issued all their 4 FT stores,
+      // which are younger than the request waited for and need not have finished)
+      if (kKind == 2 && stores_counted) wait_vector_memory_but<(kLead - 2) * (kMine + 1) + (kLead - 1) * 4 * FT>();
+      else wait_vector_memory_but<(kLead - 2) * (kMine + 1)>();
       barrier_only();
     };
     using K0 = std::integral_constant<int, 0>;
@@ -1495,11 +1498,14 @@ __global__ void __launch_bounds__(256, 1)
     // sweep 2
     step(ntile, acc_a, acc_b, K0(), 0);
     in_a = true;
+    // does every store instruction of this wave run (all its rows exist)?  The tiles stored
+    // inside the loop are whole (only the last tile of a sweep can be narrower).
+    const bool all_rows = w * 32 * FT + 32 * FT <= nrows;
     for (int t = 1; t < ntile; t += 2) {
-      step(ntile + t, acc_b, acc_a, K2(), (t - 1) << 5);
+      step(ntile + t, acc_b, acc_a, K2(), (t - 1) << 5, all_rows && t >= kLead);
       in_a = false;
       if (t + 1 < ntile) {
-        step(ntile + t + 1, acc_a, acc_b, K2(), t << 5);
+        step(ntile + t + 1, acc_a, acc_b, K2(), t << 5, all_rows && t + 1 >= kLead);
         in_a = true;
       }
     }
@@ -1512,7 +1518,7 @@ __global__ void __launch_bounds__(256, 1)
     });
     wait_vector_memory_but<0>();  // no load may still be on its way into LDS when the block ends
 #ifdef AMLIKE_OUT_STAMPS
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if ((int)blockIdx.x == jobs.lead && threadIdx.x == 0) {  // the first 256-row job
       g_out_stamps[0] = c1 - c0;
       g_out_stamps[1] = __builtin_readcyclecounter() - c1;
       g_out_stamps[2] = r1 - r0;
