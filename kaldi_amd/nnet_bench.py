@@ -8,10 +8,15 @@ import torch
 from . import nnet, synth
 
 # The layers run on fp16x2 operands (3 partial products per fp32-grade product) of the fp16
-# matrix pipe, 2500 TFLOP/s dense; the output layer and the softmax are bound by the
-# [T x 8600] matrix they stream instead (written, read, written: 12 bytes per element).
+# matrix pipe, 2500 TFLOP/s dense.  The output layer and the softmax are one kernel that forms the
+# [T x 8600] product twice and writes the result once (4 bytes per element).
 F16X2_PEAK_TFLOPS = 2500.0 / 3.0
 HBM_PEAK_TBS = 8.0
+# HBM traffic of one forward pass of this workload (256 utterances, 218 541 frames), from rocprofv3
+# --pmc passes (FETCH_SIZE, WRITE_SIZE in KB summed over the pass's kernels; FETCH_SIZE x2 as for the
+# GMM kernel): constants, not re-measured by a bench run.
+PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 6850433.0, 10107758.0
+PMC_SOURCE = "profiles/r2_c_nnet_pmc_summary.txt"
 
 
 def run(dev, stream, world, utts_per_gpu=40, steps=10, warmup=2, rank=0):
@@ -49,8 +54,17 @@ def run(dev, stream, world, utts_per_gpu=40, steps=10, warmup=2, rank=0):
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": F16X2_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / F16X2_PEAK_TFLOPS,
                      "note": "whole forward pass (GEMMs + row kernels) against the fp16 matrix peak / 3 "
-                             "partial products; the pass also streams 12 bytes per output element",
-                     "hbm_floor_ms": 12.0 * T * P / (HBM_PEAK_TBS * 1e12) * 1e3},
+                             "partial products; the output layer's product is formed twice (counted once) so "
+                             "that the [T x 8600] result is written once and never read back",
+                     "hbm_floor_ms": 4.0 * T * P / (HBM_PEAK_TBS * 1e12) * 1e3,
+                     "traffic": None},
     }
+    if T == PMC_FRAMES:
+        res["roofline"]["traffic"] = 2.0 * PMC_FETCH_KB * 1e3 + PMC_WRITE_KB * 1e3
+        res["roofline"]["traffic_detail"] = {
+            "fetch_bytes": 2.0 * PMC_FETCH_KB * 1e3, "write_bytes": PMC_WRITE_KB * 1e3,
+            "algorithmic_bytes": 4.0 * T * (40 + P),
+            "source": "constants from " + PMC_SOURCE + " (rocprofv3 --pmc passes of this workload; not "
+                      "re-measured by this run)"}
     net.close()
     return res
