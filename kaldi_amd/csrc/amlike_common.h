@@ -53,6 +53,25 @@ struct DeviceBuffer {
 // about twice the rate of the runtime's own pageable path for results of a gigabyte.
 int CopyMatrixToHost(float *out, size_t ldo, const float *d_src, int rows, int cols, hipStream_t st);
 
+// Small host-to-device uploads of tables the caller's next call rewrites (row maps, offsets): the
+// bytes are first copied into one of a few page-locked buffers, each guarded by an event, so the
+// source may change as soon as Upload returns and the copy itself is truly asynchronous.
+class PinnedUploadRing {
+ public:
+  ~PinnedUploadRing();
+  int Upload(void *d_dst, const void *src, size_t bytes, hipStream_t st);
+
+ private:
+  static constexpr int kSlots = 4;
+  struct Slot {
+    void *buf = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;
+    bool used = false;
+  } slots_[kSlots];
+  int next_ = 0;
+};
+
 // One submission of the asynchronous host-pointer entry points (*_submit / *_wait): its own
 // device input and output buffers, the event the output copy waits for, the event the
 // caller waits for, and a pinned word the non-finite flag lands in.

@@ -216,6 +216,37 @@ int CopyMatrixToHost(float *out, size_t ldo, const float *d_src, int rows, int c
   return AMLIKE_OK;
 }
 
+PinnedUploadRing::~PinnedUploadRing() {
+  for (Slot &s : slots_) {
+    if (s.ev) {
+      if (s.used) (void)hipEventSynchronize(s.ev);
+      (void)hipEventDestroy(s.ev);
+    }
+    if (s.buf) (void)hipHostFree(s.buf);
+  }
+}
+
+int PinnedUploadRing::Upload(void *d_dst, const void *src, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return AMLIKE_OK;
+  Slot &s = slots_[next_];
+  next_ = (next_ + 1) % kSlots;
+  if (!s.ev) AMLIKE_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  if (s.used) AMLIKE_HIP(hipEventSynchronize(s.ev));  // the copy that last read this buffer is done
+  if (bytes > s.bytes) {
+    if (s.buf) AMLIKE_HIP(hipHostFree(s.buf));
+    s.buf = nullptr;
+    s.bytes = 0;
+    const size_t grow = std::max<size_t>(4096, bytes + bytes / 2);
+    AMLIKE_HIP(hipHostMalloc(&s.buf, grow, hipHostMallocDefault));
+    s.bytes = grow;
+  }
+  memcpy(s.buf, src, bytes);
+  AMLIKE_HIP(hipMemcpyAsync(d_dst, s.buf, bytes, hipMemcpyHostToDevice, st));
+  AMLIKE_HIP(hipEventRecord(s.ev, st));
+  s.used = true;
+  return AMLIKE_OK;
+}
+
 int AsyncSlot::Prepare() {
   if (!computed) AMLIKE_HIP(hipEventCreateWithFlags(&computed, hipEventDisableTiming));
   if (!done) AMLIKE_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));

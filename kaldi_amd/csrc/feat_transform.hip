@@ -91,6 +91,7 @@ struct amlike_xform {
   hipStream_t stream = nullptr;
   DeviceBuffer ws_off, ws_in, ws_out, ws_spk;
   std::vector<int32_t> h_off;  // offsets followed by the per-utterance matrix index
+  PinnedUploadRing uploads;    // h_off on its way to ws_off
   std::mutex mu;
 };
 
@@ -210,7 +211,8 @@ int amlike_xform_apply_dev(amlike_xform_t *x, const float *d_in, int32_t ld,
   h[num_utts] = (int32_t)total;
   int rc = x->ws_off.Reserve(h.size() * sizeof(int32_t));
   if (rc != AMLIKE_OK) return rc;
-  AMLIKE_HIP(hipMemcpyAsync(x->ws_off.ptr, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  rc = x->uploads.Upload(x->ws_off.ptr, h.data(), h.size() * sizeof(int32_t), st);
+  if (rc != AMLIKE_OK) return rc;
   const int32_t *d_off = static_cast<const int32_t *>(x->ws_off.ptr);
   const int blocks = (int)((total + kXformFrames - 1) / kXformFrames);
   hipLaunchKernelGGL(feat_splice_affine_kernel, dim3(blocks), dim3(256), 0, st, d_in, ld, x->dim,

@@ -1662,6 +1662,7 @@ struct amlike_nnet {
   DeviceBuffer ws_a, ws_b, ws_in, ws_out, ws_utts, ws_planes;
   int *d_flags = nullptr;  // one range flag per stage (fp16x2 on trial)
   std::vector<UttMap> h_utts;
+  PinnedUploadRing uploads;  // h_utts on its way to ws_utts
   std::mutex mu;
 };
 
@@ -1919,9 +1920,10 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
   }
   rc = n->ws_utts.Reserve(maps.size() * sizeof(UttMap) + 16);
   if (rc != AMLIKE_OK) return rc;
-  if (!maps.empty())
-    AMLIKE_HIP(hipMemcpyAsync(n->ws_utts.ptr, maps.data(), maps.size() * sizeof(UttMap),
-                              hipMemcpyHostToDevice, st));
+  if (!maps.empty()) {
+    rc = n->uploads.Upload(n->ws_utts.ptr, maps.data(), maps.size() * sizeof(UttMap), st);
+    if (rc != AMLIKE_OK) return rc;
+  }
   const UttMap *d_maps = static_cast<const UttMap *>(n->ws_utts.ptr);
   AMLIKE_HIP(hipMemsetAsync(n->d_flags, 0, (n->stages.size() + 1) * sizeof(int), st));
 
