@@ -45,6 +45,24 @@ def test_score_matches_oracle(amlike_device, dim, P, G, T):
     _check(m, feats, got)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes_and_frame_counts(amlike_device, seed):
+    """Seeded random models (dimension, number and sizes of pdfs) scored on frame counts around the
+    kernel's internal boundaries: 32-frame tiles, groups of staged tiles, frame chunks per block,
+    the ragged last tile."""
+    rng = np.random.default_rng(9000 + seed)
+    dim = int(rng.integers(2, 65))
+    P = int(rng.integers(1, 400))
+    G = max(P, int(P * rng.uniform(1.0, 40.0)))
+    edges = [1, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 160, 255, 256, 257, 1023, 2047, 2048, 2049,
+             2464, 4095, 4097]
+    T = edges[seed % len(edges)] if seed % 3 else int(rng.integers(1, 6000))
+    m = synth.make_gmm(dim, P, G, seed=9100 + seed, equal_sizes=bool(seed % 5 == 0))
+    feats = synth.make_feats(m, T, seed=9200 + seed)
+    am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
+    _check(m, feats, am.LogLikelihoods(feats))
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 def test_both_kernel_families(amlike_device, mode, monkeypatch):
     """The exact-fp32 MFMA kernel and the bf16x3 kernel give the same answers."""
