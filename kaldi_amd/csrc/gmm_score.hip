@@ -2516,7 +2516,7 @@ static int LaunchScore(amlike_gmm *g, StreamLane *lane, const float *d_feats, in
       AMLIKE_HIP(hipGetLastError());
       smem = 2 * FramesTilesPerBarrier(v.W, KS, parts) * tile_bytes + (size_t)v.W * v.NT * 32 * 4 +
              (size_t)v.W * DiffTailTableBytes(v.NT);
-      if (getenv("AMLIKE_GMM_SOLO")) smem = std::max<size_t>(smem, 100 * 1024);  // tuning aid: one block per CU
+      if (getenv("AMLIKE_GMM_SOLO") && *getenv("AMLIKE_GMM_SOLO")) smem = std::max<size_t>(smem, 100 * 1024);  // tuning aid: one block per CU
       if (smem > 64 * 1024)
         AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
