@@ -237,7 +237,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = "nccl"
-    if world > 1:
+    # Under a launcher (WORLD_SIZE set) the process group is always made, one rank included: the
+    # RCCL initialisation, barrier and all-reduce of a real multi-GPU run are then the code that a
+    # one-GPU box can run too.
+    if world > 1 or "WORLD_SIZE" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         ndev = torch.cuda.device_count()
@@ -257,7 +260,7 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if dist is not None else 0)
     _lib.check(_lib.lib().amlike_init(dev.index))
 
     D, P, G = synth.GMM_CONFIGS[args.config]

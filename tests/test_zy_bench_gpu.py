@@ -54,3 +54,20 @@ def test_two_ranks_and_one_rank_agree(amlike_device):
     owner = shard_utterances(lengths, 2)
     assert "(%d frames on rank 0)" % int(lengths[owner == 0].sum()) in j2["config"]["workload"]
     assert abs(j2["value"] * j2["ms_per_step"] * 1e-3 - float(lengths.sum())) < 1.0
+
+
+def test_one_rank_under_the_launcher_takes_the_rccl_branch(amlike_device):
+    """The branch real multi-GPU runs take (RCCL process group on the rank's own device, barrier,
+    device all-reduce of the summary) with the one rank a one-GPU box allows."""
+    common = ["--steps", "2", "--warmup", "1", "--config", "rm_tri1", "--utts-per-gpu", "6",
+              "--no-nnet", "--no-cpu-baseline", "--no-host-to-host"]
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, timeout=280, cwd=ROOT,
+                         env=dict(os.environ, TORCH_DISTRIBUTED_DEBUG="INFO"))
+    assert run.returncode == 0, run.stderr[-2000:]
+    j = _line(run.stdout)
+    assert j["n_gpus"] == 1 and "rehearsal" not in j["config"]["parallelism"]
+    lengths = synth.utterance_lengths(6, 200, 1500, seed=779)
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 - float(lengths.sum())) < 1.0
