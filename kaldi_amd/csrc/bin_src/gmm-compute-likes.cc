@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../host/gmm_model.h"
+#include "../host/job_totals.h"
 #include "../host/kaldi_io.h"
 #include "../host/ordered_scorer.h"
 #include "../host/parse_options.h"
@@ -34,6 +35,13 @@ int main(int argc, char *argv[]) {
                 "repeat: several workers on one GPU)");
     po.Register("frames-per-batch", &frames_per_batch, "Frames scored per GPU launch (whole utterances)");
     po.Register("log-sum-exp-prune", &log_sum_exp_prune, "If >0, pruning value for the log-sum-exp");
+    JobTotalsOptions totals;
+    po.Register("num-procs", &totals.num_procs,
+                "Processes of a split job (one per GPU, each with its own slice of the features): their "
+                "end-of-run counts are summed with one RCCL all-reduce and logged by every process");
+    po.Register("proc-id", &totals.proc_id, "This process among --num-procs, from 0");
+    po.Register("rendezvous", &totals.rendezvous,
+                "File through which process 0 hands RCCL's id to the others; a new path for every run");
     po.Read(argc, argv);
     if (po.NumArgs() != 3) {
       po.PrintUsage();
@@ -177,6 +185,12 @@ int main(int argc, char *argv[]) {
       for (size_t w = 0; w < devices.size(); ++w)
         std::cerr << "LOG (gmm-compute-likes) worker " << w << " on GPU " << devices[w] << ": "
                   << worker_frames[w] << " frames\n";
+    if (totals.Enabled()) {
+      long long counts[3] = {num_done, num_err, num_frames};
+      AllReduceJobTotals(totals, devices[0], counts, 3);
+      std::cerr << "LOG (gmm-compute-likes) all " << totals.num_procs << " processes: computed likelihoods for "
+                << counts[0] << " utterances, failed for " << counts[1] << ", " << counts[2] << " frames\n";
+    }
     return 0;
   } catch (const std::exception &e) {
     std::cerr << e.what() << '\n';

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "../host/job_totals.h"
 #include "../host/kaldi_io.h"
 #include "../host/nnet_model.h"
 #include "../host/ordered_scorer.h"
@@ -45,6 +46,13 @@ int main(int argc, char *argv[]) {
     po.Register("devices", &device_list,
                 "Comma-separated device of each worker, instead of --device/--num-gpus (a device may "
                 "repeat: several workers on one GPU)");
+    JobTotalsOptions totals;
+    po.Register("num-procs", &totals.num_procs,
+                "Processes of a split job (one per GPU, each with its own slice of the features): their "
+                "end-of-run counts are summed with one RCCL all-reduce and logged by every process");
+    po.Register("proc-id", &totals.proc_id, "This process among --num-procs, from 0");
+    po.Register("rendezvous", &totals.rendezvous,
+                "File through which process 0 hands RCCL's id to the others; a new path for every run");
     po.Read(argc, argv);
     if (po.NumArgs() != 3) {
       po.PrintUsage();
@@ -140,6 +148,12 @@ int main(int argc, char *argv[]) {
     std::cerr << "LOG (nnet-am-compute) Processed " << num_done << " feature files, " << num_frames
               << " frames of input were processed." << (num_err ? " Failed: " + std::to_string(num_err) : std::string())
               << "\n";
+    if (totals.Enabled()) {
+      long long counts[3] = {num_done, num_err, num_frames};
+      AllReduceJobTotals(totals, devices[0], counts, 3);
+      std::cerr << "LOG (nnet-am-compute) all " << totals.num_procs << " processes: processed " << counts[0]
+                << " feature files, failed for " << counts[1] << ", " << counts[2] << " frames\n";
+    }
     return (num_done == 0 ? 1 : 0);
   } catch (const std::exception &e) {
     std::cerr << e.what() << '\n';

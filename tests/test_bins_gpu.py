@@ -158,6 +158,30 @@ def test_gmm_compute_likes_a_bad_utterance_costs_only_itself(many_utts, tmp_path
         assert np.abs(l - oracle_gmm(model, f)).max() <= TOL
 
 
+def test_job_totals_go_through_rccl(many_utts, tmp_path):
+    """--num-procs / --proc-id / --rendezvous: the end-of-run counts are all-reduced over RCCL from
+    the C++ host code (process 0 publishes RCCL's id through the rendezvous file and removes it).
+    A one-GPU box allows one process per job (RCCL refuses two ranks on a device): the job of one
+    process runs the same calls -- id, communicator, all-reduce on the device, teardown."""
+    d, _, items = many_utts
+    rdv = str(tmp_path / "rccl_id")
+    p = run("gmm-compute-likes", "--num-procs=1", "--proc-id=0", "--rendezvous=" + rdv, "--frames-per-batch=900",
+            str(d / "final.mdl"), "ark:" + str(d / "feats.ark"), "ark:" + str(tmp_path / "likes.ark"))
+    frames = sum(f.shape[0] for _, f in items)
+    assert b"all 1 processes: computed likelihoods for 40 utterances, failed for 0, %d frames" % frames in p.stderr
+    assert not os.path.exists(rdv)
+    run("gmm-compute-likes", "--frames-per-batch=900", str(d / "final.mdl"), "ark:" + str(d / "feats.ark"),
+        "ark:" + str(tmp_path / "plain.ark"))
+    assert open(str(tmp_path / "likes.ark"), "rb").read() == open(str(tmp_path / "plain.ark"), "rb").read()
+    # bad arguments are refused with a message, after the scoring, where the reduction would start
+    q = run("gmm-compute-likes", "--num-procs=2", "--proc-id=2", "--rendezvous=" + rdv, str(d / "final.mdl"),
+            "ark:" + str(d / "feats.ark"), "ark:" + str(tmp_path / "x.ark"), ok=False)
+    assert q.returncode != 0 and b"--proc-id must lie in" in q.stderr
+    q = run("gmm-compute-likes", "--num-procs=2", "--proc-id=1", str(d / "final.mdl"),
+            "ark:" + str(d / "feats.ark"), "ark:" + str(tmp_path / "x.ark"), ok=False)
+    assert q.returncode != 0 and b"--rendezvous is needed" in q.stderr
+
+
 def test_num_gpus_beyond_the_visible_devices_is_refused(many_utts, tmp_path):
     d, _, _ = many_utts
     p = run("gmm-compute-likes", "--num-gpus=64", str(d / "final.mdl"), "ark:" + str(d / "feats.ark"),
