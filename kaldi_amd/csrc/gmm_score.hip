@@ -1481,6 +1481,14 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #endif
       if (late_half && ft + 1 < ntile) group_barrier((ft + 2) / FTB);
     }
+#ifdef AMLIKE_EXTRA_SALU
+    {
+      int dummy = ft;
+#pragma unroll
+      for (int i = 0; i < AMLIKE_EXTRA_SALU; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy) : : "scc");
+      asm volatile("" ::"s"(dummy));
+    }
+#endif
     requested = AMLIKE_DIFF_EARLYLOAD && (late_half || (ft + 2) % FTB != 0);
     if (requested && !(ABL & 8)) load_b_head(tile_ptr(ft + 2));
     tail(ft, a_cur);
