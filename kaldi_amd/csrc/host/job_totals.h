@@ -10,7 +10,9 @@
 //
 // Rendezvous: process 0 writes RCCL's unique id to `rendezvous_path` (written under another
 // name, then renamed), the others wait for the file; process 0 removes it once every process
-// has joined.  The path must be new for every run.
+// has joined.  The path must be new for every run.  A process that dies before the end of its
+// run leaves the others waiting for it in the communicator set-up (RCCL has no time limit of its
+// own): the job's time limit ends them, as it ends any other stuck process of the job.
 #ifndef KALDI_AMD_CSRC_HOST_JOB_TOTALS_H_
 #define KALDI_AMD_CSRC_HOST_JOB_TOTALS_H_
 
