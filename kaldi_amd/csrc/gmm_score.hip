@@ -700,31 +700,13 @@ __device__ unsigned long long g_diff_blocks[256 * 4];  // per frame chunk: entry
 #ifndef AMLIKE_DIFF_PRE
 #define AMLIKE_DIFF_PRE 2
 #endif
-// AMLIKE_DIFF_BUFSTORE 1: the fast tail writes through a buffer descriptor that covers the
-// tile's valid rows (lanes without a segment, and rows past the end, carry offsets the
-// hardware's range check drops), and tests all of a tile's results for overflow with one
-// wave-uniform branch; 0: per-store execution masks and branches.  Measured: 19.34 ms against
-// 19.02 ms (the descriptor and the masks cost scalar registers the kernel does not have), so
-// it is off.
-#ifndef AMLIKE_DIFF_BUFSTORE
-#define AMLIKE_DIFF_BUFSTORE 0
-#endif
-// AMLIKE_DIFF_DEFER 1: the first two segment pairs of frame tile t are finished inside the pass
-// over tile t + 1, a few instructions per step between that pass's matrix instructions, so that a
-// wave's instruction stream is the same mix from end to end.  (Why it was tried: a wave that
-// issues only vector instructions beside a SIMD partner that issues only matrix instructions
-// slows the partner from 32 to 42 cycles per matrix instruction and runs at 13 cycles per
-// instruction itself, while the same instructions between a wave's own matrix instructions cost
-// a quarter of a cycle each: tools/micro/valu_rates.hip.)  Needs the gconsts in LDS and a
-// one-step fragment prefetch to fit the registers (-DAMLIKE_DIFF_GCLDS=1 -DAMLIKE_DIFF_PRE=1).
-// Measured on the 218.5 k frame workload: 19.9 ms against 19.2 ms (34.8 M against 32.9 M shader
-// cycles at the same clock), so it is off.
-#ifndef AMLIKE_DIFF_DEFER
-#define AMLIKE_DIFF_DEFER 0
+// AMLIKE_DIFF_STATICGROUPS 1: the tile loop is written out per position of a tile in its staged
+// group (see the kernel body).
+#ifndef AMLIKE_DIFF_STATICGROUPS
+#define AMLIKE_DIFF_STATICGROUPS 1
 #endif
 // Bytes of LDS per wave for the output-offset table of the differenced kernel's tail.
-// (one row of 64 offsets per segment pair, and two last rows of ~0: "nothing to write")
-constexpr int DiffTailTableBytes(int nt) { return (nt * 16 / 4 + 2) * 64 * 4; }
+constexpr int DiffTailTableBytes(int nt) { return (nt * 16 / 4) * 64 * 4; }
 
 template <int KS, int NT, int W, int OCC, int PREC, int ABL = 0>
 __global__ void __launch_bounds__(64 * W, OCC)
@@ -761,7 +743,7 @@ __global__ void __launch_bounds__(64 * W, OCC)
   uint4 *s_b = reinterpret_cast<uint4 *>(smem_h);
   float *s_gc = reinterpret_cast<float *>(smem_h + 2 * FTB * kTileU4 * 16) + w * (NT * 32);
   uint32_t *s_voff = reinterpret_cast<uint32_t *>(smem_h + 2 * FTB * kTileU4 * 16 + W * NT * 32 * 4) +
-                     w * ((kMaxPairs + 2) * 64);
+                     w * (kMaxPairs * 64);
   for (int idx = lane; idx < NT * 32; idx += 64)
     s_gc[idx] = pk.gcpack[(size_t)wc * (NT * 32) + idx];
   const int colreg = lane < kSteps ? pk.segcol[(size_t)wc * kSteps + lane] : kColDiscard;
@@ -803,8 +785,6 @@ __global__ void __launch_bounds__(64 * W, OCC)
       const int c = h ? cb : ca;
       s_voff[k * 64 + lane] = c >= 0 ? ((uint32_t)j * (uint32_t)ar.ldo + (uint32_t)c) * 4u : ~0u;
     }
-    s_voff[kMaxPairs * 64 + lane] = ~0u;
-    s_voff[(kMaxPairs + 1) * 64 + lane] = ~0u;
     const bool part_here = lane < nseg && colreg < kColDiscard;
     fast_chunk = AMLIKE_DIFF_FASTTAIL && __builtin_amdgcn_ballot_w64(part_here) == 0 &&
                  (unsigned)ar.ldo < (1u << 24);
@@ -977,8 +957,7 @@ __global__ void __launch_bounds__(64 * W, OCC)
     }
   };
   accvec sv;
-  auto pass = [&](const int ft, accvec &acc_c, accvec &acc_n) __attribute__((always_inline)) {
-    const uint4 *bt = tile_ptr(ft + 1);
+  auto pass_at = [&](const uint4 *bt, accvec &acc_c, accvec &acc_n) __attribute__((always_inline)) {
     float s_ = 0.0f;
 #ifdef AMLIKE_DIFF_STAMPS
     const unsigned long long st0 = AMLIKE_STAMP();
@@ -1026,6 +1005,9 @@ __global__ void __launch_bounds__(64 * W, OCC)
     ++stamp_tiles;
 #endif
   };
+  auto pass = [&](const int ft, accvec &acc_c, accvec &acc_n) __attribute__((always_inline)) {
+    pass_at(tile_ptr(ft + 1), acc_c, acc_n);
+  };
 
   // General tail: the segments of this wave's chunk for frame tile ft, two per iteration:
   // lanes 0-31 finish segment 2k and lanes 32-63 segment 2k+1 of the same 32 frames.  One
@@ -1071,11 +1053,10 @@ __global__ void __launch_bounds__(64 * W, OCC)
   // Fast tail (whole frame tiles of chunks without split-pdf parts): two pairs of segments per
   // step, in straight-line code so that their dependent chains overlap; segment positions from
   // endw, output offsets from s_voff, stores relative to the tile's first output row.
-  auto tail_fast = [&](const int ft, const accvec &acc_c) __attribute__((always_inline)) {
-    const int t0 = t_begin + (ft << 5);
+  auto tail_fast_at = [&](const int t0, const accvec &acc_c) __attribute__((always_inline)) {
     // Keep the packed words opaque per tile: the field extraction (scalar unit, cheap) is redone
     // every tile instead of every field living in a scalar register of its own.
-#if __HIP_DEVICE_COMPILE__ && !AMLIKE_DIFF_DEFER
+#if __HIP_DEVICE_COMPILE__
 #pragma unroll
     for (int q = 0; q < (kMaxPairs + 2) / 3; ++q) asm volatile("" : "+s"(endw[q]));
 #endif
@@ -1107,42 +1088,6 @@ __global__ void __launch_bounds__(64 * W, OCC)
       v0 = finish(ea0, eb0, sa0, sb0);
       v1 = finish(ea1, eb1, sa1, sb1);
     };
-#if AMLIKE_DIFF_BUFSTORE && __HIP_DEVICE_COMPILE__
-    // Descriptor of the tile's rows inside this block's frames: an offset at or beyond
-    // num_records (a lane without a segment carries ~0; a row past t_end lies beyond) is dropped.
-    const uint32_t valid_bytes = (uint32_t)min(32, t_end - t0) * (uint32_t)ar.ldo * 4u;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char *>(ar.out) + (size_t)t0 * (size_t)ar.ldo * sizeof(float), 0, valid_bytes, 0x00020000);
-    bool bad = false;
-#pragma unroll
-    for (int kk = 0; kk < (kMaxPairs + 1) / 2; ++kk) {
-      if (2 * kk >= npair) break;
-      float v0, v1;
-      uint32_t voff0, voff1;
-      step_values(kk, v0, v1, voff0, voff1);
-      if (!(ABL & 1)) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rsrc, voff0, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rsrc, voff1, 0, 0);
-      } else {
-        pin_order(v0);
-        pin_order(v1);
-      }
-      bad |= (voff0 < valid_bytes && !(fabsf(v0) <= kMaxAbsLogLike)) ||
-             (voff1 < valid_bytes && !(fabsf(v1) <= kMaxAbsLogLike));
-    }
-    // Rare: some result of this tile is out of range.  The values are formed again and the
-    // offending (frame, pdf) pairs go to the repair list.
-    if (!ABL && __builtin_amdgcn_ballot_w64(bad) != 0) {
-      for (int kk = 0; 2 * kk < npair; ++kk) {
-        float v[2];
-        uint32_t vo[2];
-        step_values(kk, v[0], v[1], vo[0], vo[1]);
-        for (int q = 0; q < 2; ++q)
-          if (vo[q] < valid_bytes && !(fabsf(v[q]) <= kMaxAbsLogLike))
-            report_overflow(t0 + j, (int)(vo[q] / 4u - (uint32_t)j * (uint32_t)ar.ldo));
-      }
-    }
-#else
 #pragma unroll
     for (int kk = 0; kk < (kMaxPairs + 1) / 2; ++kk) {
       if (2 * kk >= npair) break;
@@ -1155,7 +1100,9 @@ __global__ void __launch_bounds__(64 * W, OCC)
       emit_at(t0, v0, voff0);
       emit_at(t0, v1, voff1);
     }
-#endif
+  };
+  auto tail_fast = [&](const int ft, const accvec &acc_c) __attribute__((always_inline)) {
+    tail_fast_at(t_begin + (ft << 5), acc_c);
   };
 
   auto tail = [&](const int ft, const accvec &acc_c) __attribute__((always_inline)) {
@@ -1168,7 +1115,7 @@ __global__ void __launch_bounds__(64 * W, OCC)
     if (ABL & 4) {
       accvec keep = sv;
       pin_order(keep);
-    } else if (fast_chunk && (AMLIKE_DIFF_BUFSTORE || t_begin + (ft << 5) + 32 <= t_end)) {
+    } else if (fast_chunk && t_begin + (ft << 5) + 32 <= t_end) {
       tail_fast(ft, acc_c);
     } else {
       tail_general(ft, acc_c);
@@ -1252,191 +1199,6 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #endif
     return;
   }
-#if AMLIKE_DIFF_DEFER
-  if constexpr (ABL == 0 && !AMLIKE_DIFF_PP) {
-    // Deferred finish.  Values that cross from the pass over one tile into the pass over the
-    // next: the reference score and the first difference of segments 0/1 (lanes 0-31 / 32-63)
-    // and of segments 2/3, read from the accumulators late in the pass that owns them.
-    // (d_x: already as 1 + exp2(first difference))
-    float d_ref0 = 0.0f, d_x0 = 1.0f, d_ref1 = 0.0f, d_x1 = 1.0f;
-    const bool late_half_d = AMLIKE_DIFF_STAGGER && W == 8 && FTB >= 2 && w >= W / 2;
-    auto group_barrier_d = [&](const int g) __attribute__((always_inline)) {
-      __syncthreads();
-      if (g + 1 < ngroup) stage(g + 1);
-    };
-    constexpr int kPreSlots = 4;
-    constexpr int kSlots = kPreSlots + kSteps;
-    // output column of this lane's element of segment pair `row` of s_voff
-    auto colreg_of = [&](const int row, int) -> int {
-      return (int)(s_voff[row * 64 + lane] / 4u - (uint32_t)j * (uint32_t)ar.ldo);
-    };
-    // Pass over tile ft (scores in acc_c, sums into sv) with the matrix instructions of tile
-    // ft + 1 (into acc_n) and the finish of tile ft - 1: its sums are still in sv when the pass
-    // starts and are collected in the first slots, before the first step overwrites sv[0].
-    // vrow: row of s_voff for the first pair of tile ft - 1, or the row of ~0 when there is no
-    // such tile; prev_t0: first frame of tile ft - 1.
-    auto pass_d = [&](const int ft, accvec &acc_c, accvec &acc_n, const int vrow, const int prev_t0)
-                      __attribute__((always_inline)) {
-      const uint4 *bt = tile_ptr(ft + 1);
-      auto end_of = [&](int seg) -> int { return (endw[seg / 6] >> (5 * (seg % 6))) & 31; };
-      const int ea0 = end_of(0), eb0 = end_of(1), ea1 = end_of(2), eb1 = end_of(3);
-      const int sb0 = min(ea0 + 1, kSteps - 1), sa1 = min(eb0 + 1, kSteps - 1), sb1 = min(ea1 + 1, kSteps - 1);
-      char *prev_base = reinterpret_cast<char *>(ar.out) + (size_t)prev_t0 * (size_t)ar.ldo * sizeof(float);
-      __builtin_amdgcn_s_setprio(2);
-      auto mfmas_of = [&](const int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int n = (slot * kMfma) / kSlots; n < ((slot + 1) * kMfma) / kSlots; ++n) mfma_n(acc_n, bt, n);
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      float f0, f1;  // the two results on their way: sum, log, value
-      {
-        float u0, u1;
-        mfmas_of(0);
-        u0 = sv[ea0];
-        u1 = sv[eb0];
-        pin_order(u0);
-        pin_order(u1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas_of(1);
-        const auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(u0), __float_as_uint(u1), false, false);
-        f0 = d_x0 + (__uint_as_float(ss[0]) + __uint_as_float(ss[1]));
-        pin_order(f0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      {
-        float w0, w1;
-        mfmas_of(2);
-        w0 = sv[ea1];
-        w1 = sv[eb1];
-        pin_order(w0);
-        pin_order(w1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas_of(3);
-        const auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(w0), __float_as_uint(w1), false, false);
-        f1 = d_x1 + (__uint_as_float(ss[0]) + __uint_as_float(ss[1]));
-        pin_order(f1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      float s_ = 0.0f;
-      float e_cur = fast_exp2(acc_c[0]);
-      uint32_t voff0 = ~0u, voff1 = ~0u;
-      float a0, a1, b0, b1;
-      bool bad0 = false, bad1 = false;
-#pragma unroll
-      for (int st = 0; st < kSteps; ++st) {
-        mfmas_of(kPreSlots + st);
-        float e_next = 0.0f;
-        if (st + 1 < kSteps) e_next = fast_exp2(acc_c[st + 1]);
-        s_ = fmaf(s_, keepf[st], e_cur);
-        pin_order(e_next);
-        pin_order(s_);
-        e_cur = e_next;
-        sv[st] = s_;
-        // one small piece of the previous tile's finish, or of this tile's collection, per step
-        if (st == 0) {
-          f0 = fast_log2(f0);
-          pin_order(f0);
-        } else if (st == 1) {
-          f1 = fast_log2(f1);
-          pin_order(f1);
-        } else if (st == 2) {
-          voff0 = s_voff[vrow * 64 + lane];
-          f0 = fmaf(f0, kLn2, d_ref0);
-          pin_order(f0);
-        } else if (st == 3) {
-          voff1 = s_voff[(vrow + 1) * 64 + lane];
-          f1 = fmaf(f1, kLn2, d_ref1);
-          pin_order(f1);
-        } else if (st == 4) {
-          if (voff0 != ~0u) *reinterpret_cast<float *>(prev_base + voff0) = f0;
-          bad0 = voff0 != ~0u && !(fabsf(f0) <= kMaxAbsLogLike);
-        } else if (st == 5) {
-          if (voff1 != ~0u) *reinterpret_cast<float *>(prev_base + voff1) = f1;
-          bad1 = voff1 != ~0u && !(fabsf(f1) <= kMaxAbsLogLike);
-        } else if (st == kSteps - 4) {
-          a0 = acc_c[0];
-          a1 = acc_c[sb0];
-          pin_order(a0);
-          pin_order(a1);
-        } else if (st == kSteps - 3) {
-          b0 = acc_c[sa1];
-          b1 = acc_c[sb1];
-          pin_order(b0);
-          pin_order(b1);
-        } else if (st == kSteps - 2) {
-          const auto xx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
-          d_ref0 = __uint_as_float(xx[0]);
-          d_x0 = 1.0f + fast_exp2(__uint_as_float(xx[1]));
-          pin_order(d_ref0);
-          pin_order(d_x0);
-        } else if (st == kSteps - 1) {
-          const auto xx = __builtin_amdgcn_permlane32_swap(__float_as_uint(b0), __float_as_uint(b1), false, false);
-          d_ref1 = __uint_as_float(xx[0]);
-          d_x1 = 1.0f + fast_exp2(__uint_as_float(xx[1]));
-          pin_order(d_ref1);
-          pin_order(d_x1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      // Rare: a result of the previous tile is out of range; it goes to the repair list.
-      if (__builtin_amdgcn_ballot_w64(bad0 || bad1) != 0) {
-        if (bad0) report_overflow(prev_t0 + j, colreg_of(vrow, 0));
-        if (bad1) report_overflow(prev_t0 + j, colreg_of(vrow + 1, 0));
-      }
-    };
-    // Segment pairs beyond the first two of tile ft: finished at once, as in tail_fast.
-    auto tail_rest = [&](const int ft, const accvec &acc_c) __attribute__((always_inline)) {
-      const int t0 = t_begin + (ft << 5);
-      auto end_of = [&](int seg) -> int { return (endw[seg / 6] >> (5 * (seg % 6))) & 31; };
-      for (int kk = 1; 2 * kk < npair; ++kk) {
-        float v[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int pa = 4 * kk + 2 * q;  // first segment of the pair
-          const int ea = end_of(pa), eb = end_of(pa + 1);
-          const int sa = min(end_of(pa - 1) + 1, kSteps - 1), sb = min(ea + 1, kSteps - 1);
-          const auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(sv[ea]), __float_as_uint(sv[eb]), false, false);
-          const auto xx = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_c[sa]), __float_as_uint(acc_c[sb]), false, false);
-          v[q] = fmaf(fast_log2((1.0f + fast_exp2(__uint_as_float(xx[1]))) +
-                                (__uint_as_float(ss[0]) + __uint_as_float(ss[1]))),
-                      kLn2, __uint_as_float(xx[0]));
-        }
-        emit_at(t0, v[0], s_voff[(2 * kk) * 64 + lane]);
-        emit_at(t0, v[1], s_voff[(2 * kk + 1) * 64 + lane]);
-      }
-    };
-    bool requested_d = false;
-    auto tile_body_d = [&](const int ft, accvec &a_cur, accvec &a_next) __attribute__((always_inline)) {
-      const int fn = ft + 1;
-      if (fn % FTB == 0 && !late_half_d) group_barrier_d(fn / FTB);
-      load_gc(a_next);
-      if (!requested_d) load_b_head(tile_ptr(fn));
-      pass_d(ft, a_cur, a_next, (ft > 0 && fast_chunk) ? 0 : kMaxPairs, t_begin + (max(ft - 1, 0) << 5));
-      if ((ft + 2) % FTB == 0) {
-        wait_vector_memory();
-        if (late_half_d && ft + 1 < ntile) group_barrier_d((ft + 2) / FTB);
-      }
-      requested_d = AMLIKE_DIFF_EARLYLOAD && (late_half_d || (ft + 2) % FTB != 0);
-      if (requested_d) load_b_head(tile_ptr(ft + 2));
-      if (!fast_chunk) {  // a chunk with a part of a split pdf: nothing is deferred
-        tail_general(ft, a_cur);
-      } else if (ft + 1 < ntile) {
-        if (npair > 2) tail_rest(ft, a_cur);
-      } else if (t_begin + (ft << 5) + 32 <= t_end) {  // the block's last tile: finished at once
-        tail_fast(ft, a_cur);
-      } else {
-        tail_general(ft, a_cur);
-      }
-    };
-    for (int ft = 0; ft < ntile; ft += 2) {
-      tile_body_d(ft, acc_cur, acc_alt);
-      if (ft + 1 >= ntile) break;
-      tile_body_d(ft + 1, acc_alt, acc_cur);
-    }
-    return;
-  }
-#endif
   // Every wave runs pass and tail of a tile back to back; one barrier per staged group.  The two
   // waves of a SIMD (w and w + W/2) settle into taking turns on the matrix pipe -- one in its
   // pass while the other is in its tail -- so the barrier of a group sits half a tile apart in
@@ -1493,7 +1255,71 @@ __global__ void __launch_bounds__(64 * W, OCC)
     if (requested && !(ABL & 8)) load_b_head(tile_ptr(ft + 2));
     tail(ft, a_cur);
   };
-  for (int ft = 0; ft < ntile; ft += 2) {
+  int ft_from = 0;
+#if AMLIKE_DIFF_STATICGROUPS
+  // Every group but a block's last holds FTB whole frame tiles and has a successor: for those the
+  // tile's position in its group is spelled out (FTB copies of the tile body), so that where the
+  // barrier, the wait for the staging loads and the fragment requests sit, and where the
+  // fragments lie in LDS, cost no scalar arithmetic or branches per tile.  Same protocol as
+  // tile_body; the block's last group runs through tile_body.
+  if constexpr (FTB == 4 && W == 8 && ABL == 0) {
+    if (ngroup > 1) {
+      const uint4 *buf_cur = s_b + lane, *buf_next = s_b + FTB * kTileU4 + lane;  // this group's / the next group's tiles
+      int t0 = t_begin;
+      load_b_head(buf_cur + kTileU4);  // tile 1
+      auto tail_at = [&](const accvec &acc_c) __attribute__((always_inline)) {
+#ifdef AMLIKE_DIFF_STAMPS
+        const unsigned long long st0 = AMLIKE_STAMP();
+#endif
+        if (fast_chunk) {
+          tail_fast_at(t0, acc_c);
+        } else {
+          tail_general((t0 - t_begin) >> 5, acc_c);
+        }
+#ifdef AMLIKE_DIFF_STAMPS
+        stamp_tail += AMLIKE_STAMP() - st0;
+#endif
+        t0 += 32;
+      };
+      for (int g = 0; g + 1 < ngroup; ++g) {
+        // tile 0 of the group
+        load_gc(acc_alt);
+        pass_at(buf_cur + kTileU4, acc_cur, acc_alt);
+        load_b_head(buf_cur + 2 * kTileU4);
+        tail_at(acc_cur);
+        // tile 1
+        load_gc(acc_cur);
+        pass_at(buf_cur + 2 * kTileU4, acc_alt, acc_cur);
+        load_b_head(buf_cur + 3 * kTileU4);
+        tail_at(acc_alt);
+        // tile 2: its pass is the last to read this group's tiles
+        load_gc(acc_alt);
+        pass_at(buf_cur + 3 * kTileU4, acc_cur, acc_alt);
+        wait_vector_memory();
+        if (late_half) {
+          group_barrier(g + 1);
+          load_b_head(buf_next);
+        }
+        tail_at(acc_cur);
+        // tile 3: its pass reads the next group's first tile
+        if (!late_half) {
+          group_barrier(g + 1);
+          load_b_head(buf_next);
+        }
+        load_gc(acc_cur);
+        pass_at(buf_next, acc_alt, acc_cur);
+        load_b_head(buf_next + kTileU4);
+        tail_at(acc_alt);
+        const uint4 *swap = buf_cur;
+        buf_cur = buf_next;
+        buf_next = swap;
+      }
+      ft_from = (ngroup - 1) * FTB;
+      requested = true;
+    }
+  }
+#endif
+  for (int ft = ft_from; ft < ntile; ft += 2) {
     tile_body(ft, acc_cur, acc_alt);
     if (ft + 1 >= ntile) break;
     tile_body(ft + 1, acc_alt, acc_cur);
