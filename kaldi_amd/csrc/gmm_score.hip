@@ -2054,38 +2054,46 @@ static int PackModel(amlike_gmm *g, const float *gconsts, const float *miv, cons
   }
   const Variant &v = *vp;
 
-  // Assign pieces to chunks.
+  // Assign pieces to chunks.  A chunk takes the first piece not yet placed and, of the kLook
+  // pieces behind it, the set that fills the rest of the chunk best (subset sum over their slot
+  // counts; of two sets with the same sum the one found first, i.e. made of nearer pieces).
+  // Pieces stay in pdf order inside a chunk, and a chunk's pdfs lie within kLook of each other:
+  // neighbouring output columns are still written by neighbouring chunks.
   std::vector<std::vector<Piece>> chunks;
   {
     const int kLook = 48;
     std::vector<char> used(pieces.size(), 0);
     size_t head = 0;
-    while (head < pieces.size()) {
-      std::vector<Piece> cur;
-      int left = cap;
-      for (;;) {
-        while (head < pieces.size() && used[head]) ++head;
-        if (head >= pieces.size()) break;
-        int pick = -1;
-        const int need_head = slots_of(pieces[head].count);
-        if (need_head <= left) {
-          pick = (int)head;
-        } else {
-          int best = 0;
-          for (size_t k = head + 1; k < pieces.size() && k < head + kLook; ++k) {
-            if (used[k]) continue;
-            const int need = slots_of(pieces[k].count);
-            if (need <= left && need > best) {
-              best = need;
-              pick = (int)k;
-            }
+    std::vector<int> via_piece(cap + 1), via_sum(cap + 1);
+    while (true) {
+      while (head < pieces.size() && used[head]) ++head;
+      if (head >= pieces.size()) break;
+      used[head] = 1;
+      const int left = cap - slots_of(pieces[head].count);
+      // via_piece[s]: the piece that first reached sum s (-1: not reached), via_sum[s]: from which sum
+      std::fill(via_piece.begin(), via_piece.end(), -1);
+      std::vector<char> reached(cap + 1, 0);
+      reached[0] = 1;
+      for (size_t k = head + 1; k < pieces.size() && k < head + kLook; ++k) {
+        if (used[k]) continue;
+        const int need = slots_of(pieces[k].count);
+        for (int sum = left - need; sum >= 0; --sum)
+          if (reached[sum] && !reached[sum + need]) {
+            reached[sum + need] = 1;
+            via_piece[sum + need] = (int)k;
+            via_sum[sum + need] = sum;
           }
-        }
-        if (pick < 0) break;
-        used[pick] = 1;
-        cur.push_back(pieces[pick]);
-        left -= slots_of(pieces[pick].count);
-        if (left == 0) break;
+      }
+      int best = left;
+      while (!reached[best]) --best;
+      std::vector<int> taken;
+      for (int sum = best; sum > 0; sum = via_sum[sum]) taken.push_back(via_piece[sum]);
+      std::sort(taken.begin(), taken.end());
+      std::vector<Piece> cur;
+      cur.push_back(pieces[head]);
+      for (int k : taken) {
+        used[k] = 1;
+        cur.push_back(pieces[k]);
       }
       chunks.push_back(cur);
     }
@@ -2272,8 +2280,9 @@ static int LaunchScore(amlike_gmm *g, StreamLane *lane, const float *d_feats, in
   // operands (NT*D registers per lane) is amortised over many frame tiles, enough
   // blocks to keep every CU busy to the end, and equal shares (no short last chunk).
   const int cus = std::max(1, NumComputeUnits());
-  int target = 2048;
-  if (const char *e = getenv("AMLIKE_GMM_FPB")) target = std::max(32, atoi(e));  // tuning aid
+  int target = 4096;  // (measured on 218.5 k frames: 2048 17.57, 3072 17.42, 4096 17.38, 6144 17.34, 8192 17.42 ms)
+  if (const char *e = getenv("AMLIKE_GMM_FPB_TARGET")) target = std::max(64, atoi(e));  // tuning aid: the chooser's aim
+  if (const char *e = getenv("AMLIKE_GMM_FPB")) target = std::max(32, atoi(e));  // tuning aid: exactly this
   int nby = std::max(1, (T + target - 1) / target);
   // Small batches: split the frames further so that every CU has a block.
   while (nbx * nby < cus && (T + nby - 1) / nby > 64) ++nby;
