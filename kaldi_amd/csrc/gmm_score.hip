@@ -70,6 +70,11 @@ constexpr int FramesTilesPerBarrier(int waves, int ks, int parts = 3) {
   const int budget = waves >= 8 ? 120 * 1024 : 60 * 1024, pair = 2 * ks * parts * 64 * 16;
   return budget / pair >= 4 ? 4 : budget / pair >= 2 ? 2 : 1;
 }
+// fp16x2 operands: mask on the bits of the low parts (tuning aid: fewer mantissa bits switch less
+// in the matrix pipe; 0xFFFF keeps them all).
+#ifndef AMLIKE_F16_LO_MASK
+#define AMLIKE_F16_LO_MASK 0xFFFF
+#endif
 // fp16x2 operands: scaled feature values beyond this magnitude send the launch to the
 // wide-range (bf16x3) kernel.
 constexpr float kF16Limit = 60000.0f;
@@ -429,7 +434,7 @@ __global__ void __launch_bounds__(256)
     const _Float16 h1 = static_cast<_Float16>(x);
     const _Float16 h2 = static_cast<_Float16>(x - static_cast<float>(h1));
     p1[jj] = __builtin_bit_cast(unsigned short, h1);
-    p2[jj] = __builtin_bit_cast(unsigned short, h2);
+    p2[jj] = __builtin_bit_cast(unsigned short, h2) & (unsigned short)AMLIKE_F16_LO_MASK;
   }
   auto pack = [](const unsigned short *p) {
     return make_uint4(p[0] | (unsigned)p[1] << 16, p[2] | (unsigned)p[3] << 16,
@@ -1865,6 +1870,7 @@ static inline void SplitF16x2(float x, uint16_t p[2]) {
   const _Float16 h2 = static_cast<_Float16>(x - static_cast<float>(h1));
   memcpy(&p[0], &h1, 2);
   memcpy(&p[1], &h2, 2);
+  p[1] &= (uint16_t)AMLIKE_F16_LO_MASK;
 }
 
 // Chooses, for every k-row of the contraction (kind 0: miv_d * x_d, kind 1: -0.5 iv_d * x_d^2),
