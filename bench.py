@@ -65,8 +65,8 @@ F16X2_PRODUCTS = 3
 MEASURED_F16_MFMA_TFLOPS = 2419.0
 MEASURED_F16_MFMA_TFLOPS_RANDOM = 1700.0
 # (profiles/r2_*_pmc_summary.txt: the current kernel)
-PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 2484960.0, 9296680.0
-PMC_SOURCE = "profiles/r2_h_gmm_diff_pmc_summary.txt"
+PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 2485900.0, 9292620.0
+PMC_SOURCE = "profiles/r2_i_gmm_diff_pmc_summary.txt"
 
 
 def _cpu_model():
