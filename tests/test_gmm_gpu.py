@@ -420,6 +420,9 @@ def test_swbd_tri4_full_size(amlike_device, monkeypatch):
     am = gmm.AmDiagGmm(m["weights"], m["means_invvars"], m["inv_vars"], m["pdf_offsets"])
     got = am.LogLikelihoods(feats)
     assert "gmm_score_diff_kernel" in am.kernel_info() and "f16x2" in am.kernel_info()
+    # the pdfs fill the wave chunks' slots almost to what the even-slot padding allows (0.979)
+    fill = float(am.kernel_info().split("fill=")[1].split()[0])
+    assert fill >= 0.97, am.kernel_info()
     assert np.isfinite(got).all()
     # (a) oracle on 48 frames spread over the batch
     rows = np.linspace(0, T - 1, 48).astype(int)
