@@ -122,10 +122,12 @@ int amlike_gmm_score_wait(amlike_gmm_t *gmm, int32_t ticket);
 
 /* Device-pointer form: feats/out are device memory, the work is enqueued on
  * `stream` (a hipStream_t, or NULL for the default stream) and NOT waited for.
- * The NaN/Inf flag of the most recent launch is read with amlike_gmm_poll().
- * A handle owns one set of device scratch buffers (operand images of the features,
- * partial sums): launches on one handle must be ordered, i.e. issued on one stream or
- * serialised by the caller.  For concurrent scoring create one handle per thread. */
+ * The NaN/Inf flag of the launches made on `stream` is read with amlike_gmm_poll(gmm, stream).
+ * A handle keeps one set of working memory (operand images of the features, repair list,
+ * partial sums, control and flag words) per stream it is called with, for the 8 streams used
+ * last: calls on different streams of one handle may be made from different threads and run on
+ * the GPU at the same time; calls on one stream run in order.  (A ninth stream takes over the
+ * working memory of the stream unused for longest, after a device-wide synchronisation.) */
 int amlike_gmm_score_dev(amlike_gmm_t *gmm, const float *d_feats, int32_t T, int32_t ld,
                          int32_t feat_dim, float log_sum_exp_prune, float *d_out,
                          int32_t ldo, void *stream);
@@ -140,13 +142,14 @@ int amlike_gmm_score_dev(amlike_gmm_t *gmm, const float *d_feats, int32_t T, int
  * model need more than that (the swbd tri4 shape: up to about 6 000 frames per call), for models
  * the fused kernels do not cover (dimension above 64), and before amlike_init.  Every call on a
  * GPU uses that GPU's one array: calls that overlap in time on one GPU, from any handle or
- * stream, race; issue them on one stream or order them yourself. */
+ * stream, race; issue them on one stream or order them yourself.  Its NaN/Inf report is kept
+ * per handle, not per stream: amlike_gmm_poll(gmm, any stream) returns it. */
 int amlike_gmm_score_dev_noalloc(amlike_gmm_t *gmm, const float *d_feats, int32_t T, int32_t ld,
                                  int32_t feat_dim, float *d_out, int32_t ldo, void *stream);
 size_t amlike_gmm_noalloc_scratch_bytes(void);
 
-/* Waits for `stream` and returns AMLIKE_OK or AMLIKE_ENONFINITE for the
- * launches since the previous poll. */
+/* Waits for `stream` and returns AMLIKE_OK or AMLIKE_ENONFINITE for the launches made on
+ * that stream (and the handle's amlike_gmm_score_dev_noalloc calls) since the previous poll. */
 int amlike_gmm_poll(amlike_gmm_t *gmm, void *stream);
 
 /* Replaces DiagGmm::LogLikelihoods(Matrix) (gmm/diag-gmm.cc:546-562) and, row by

@@ -1,6 +1,8 @@
 // gmm-compute-likes on MI355X: same command line, inputs and outputs as the reference
 // binary (/root/reference/src/gmmbin/gmm-compute-likes.cc:30-89); the frame x pdf loop
-// (:71-77) runs on the GPU through libamlike.  Extra options: --device, --num-gpus (one worker
+// (:71-77) runs on the GPU through libamlike.  One deviation: where the reference aborts on the
+// first non-finite log-likelihood (status -1, nothing more written), this program reports the
+// utterance, scores and writes all the others, and then returns -1.  Extra options: --device, --num-gpus (one worker
 // thread and one copy of the model per GPU, outputs still in input order), and
 // --frames-per-batch (utterances are scored together in batches of about that many frames,
 // two batches in flight per GPU).
@@ -42,6 +44,8 @@ int main(int argc, char *argv[]) {
     po.Register("proc-id", &totals.proc_id, "This process among --num-procs, from 0");
     po.Register("rendezvous", &totals.rendezvous,
                 "File through which process 0 hands RCCL's id to the others; a new path for every run");
+    po.Register("rendezvous-timeout", &totals.rendezvous_timeout,
+                "Seconds to wait at program start for process 0 to publish RCCL's id");
     po.Read(argc, argv);
     if (po.NumArgs() != 3) {
       po.PrintUsage();
@@ -49,6 +53,16 @@ int main(int argc, char *argv[]) {
     }
     const std::vector<int32> devices = ParseDeviceList(device_list, num_gpus, device);
     CheckAmlike(amlike_init(devices[0]));
+    // The processes of a split job join their communicator now, while all of them are starting up.
+    std::unique_ptr<JobTotals> job_totals;
+    if (totals.Enabled()) {
+      if (totals.num_procs < 1 || totals.proc_id < 0 || totals.proc_id >= totals.num_procs)
+        KALDI_AMD_ERR("--proc-id must lie in [0, --num-procs)");
+      if (totals.rendezvous.empty()) KALDI_AMD_ERR("--rendezvous is needed with --num-procs");
+      job_totals.reset(new JobTotals(totals, devices[0]));
+      if (!job_totals->Joined())
+        std::cerr << "WARNING (gmm-compute-likes) " << job_totals->Error() << "; this process will log its own counts only\n";
+    }
     AmDiagGmm am_gmm;
     {
       bool binary;
@@ -185,13 +199,18 @@ int main(int argc, char *argv[]) {
       for (size_t w = 0; w < devices.size(); ++w)
         std::cerr << "LOG (gmm-compute-likes) worker " << w << " on GPU " << devices[w] << ": "
                   << worker_frames[w] << " frames\n";
-    if (totals.Enabled()) {
+    if (job_totals && job_totals->Joined()) {
       long long counts[3] = {num_done, num_err, num_frames};
-      AllReduceJobTotals(totals, devices[0], counts, 3);
-      std::cerr << "LOG (gmm-compute-likes) all " << totals.num_procs << " processes: computed likelihoods for "
-                << counts[0] << " utterances, failed for " << counts[1] << ", " << counts[2] << " frames\n";
+      if (job_totals->AllReduce(counts, 3))
+        std::cerr << "LOG (gmm-compute-likes) all " << totals.num_procs << " processes: computed likelihoods for "
+                  << counts[0] << " utterances, failed for " << counts[1] << ", " << counts[2] << " frames\n";
+      else  // the scoring run itself is complete: its exit status stands
+        std::cerr << "WARNING (gmm-compute-likes) " << job_totals->Error() << "; the job's totals are not available\n";
     }
-    return 0;
+    // An utterance with a non-finite log-likelihood ends the reference's run with status -1
+    // ("Invalid answer", gmm/diag-gmm.cc:523 -> gmm-compute-likes.cc:85-88).  Here the other
+    // utterances are still scored and written, but the status says that keys are missing.
+    return num_err > 0 ? -1 : 0;
   } catch (const std::exception &e) {
     std::cerr << e.what() << '\n';
     return -1;

@@ -53,6 +53,8 @@ int main(int argc, char *argv[]) {
     po.Register("proc-id", &totals.proc_id, "This process among --num-procs, from 0");
     po.Register("rendezvous", &totals.rendezvous,
                 "File through which process 0 hands RCCL's id to the others; a new path for every run");
+    po.Register("rendezvous-timeout", &totals.rendezvous_timeout,
+                "Seconds to wait at program start for process 0 to publish RCCL's id");
     po.Read(argc, argv);
     if (po.NumArgs() != 3) {
       po.PrintUsage();
@@ -60,6 +62,16 @@ int main(int argc, char *argv[]) {
     }
     const std::vector<int32> devices = ParseDeviceList(device_list, num_gpus, device);
     CheckAmlike(amlike_init(devices[0]));
+    // The processes of a split job join their communicator now, while all of them are starting up.
+    std::unique_ptr<JobTotals> job_totals;
+    if (totals.Enabled()) {
+      if (totals.num_procs < 1 || totals.proc_id < 0 || totals.proc_id >= totals.num_procs)
+        KALDI_AMD_ERR("--proc-id must lie in [0, --num-procs)");
+      if (totals.rendezvous.empty()) KALDI_AMD_ERR("--rendezvous is needed with --num-procs");
+      job_totals.reset(new JobTotals(totals, devices[0]));
+      if (!job_totals->Joined())
+        std::cerr << "WARNING (nnet-am-compute) " << job_totals->Error() << "; this process will log its own counts only\n";
+    }
     TransitionModel trans_model;
     AmNnet am_nnet;
     {
@@ -148,11 +160,13 @@ int main(int argc, char *argv[]) {
     std::cerr << "LOG (nnet-am-compute) Processed " << num_done << " feature files, " << num_frames
               << " frames of input were processed." << (num_err ? " Failed: " + std::to_string(num_err) : std::string())
               << "\n";
-    if (totals.Enabled()) {
+    if (job_totals && job_totals->Joined()) {
       long long counts[3] = {num_done, num_err, num_frames};
-      AllReduceJobTotals(totals, devices[0], counts, 3);
-      std::cerr << "LOG (nnet-am-compute) all " << totals.num_procs << " processes: processed " << counts[0]
-                << " feature files, failed for " << counts[1] << ", " << counts[2] << " frames\n";
+      if (job_totals->AllReduce(counts, 3))
+        std::cerr << "LOG (nnet-am-compute) all " << totals.num_procs << " processes: processed " << counts[0]
+                  << " feature files, failed for " << counts[1] << ", " << counts[2] << " frames\n";
+      else  // the scoring run itself is complete: its exit status stands
+        std::cerr << "WARNING (nnet-am-compute) " << job_totals->Error() << "; the job's totals are not available\n";
     }
     return (num_done == 0 ? 1 : 0);
   } catch (const std::exception &e) {

@@ -1334,6 +1334,10 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #endif
 }
 
+__global__ void gmm_clear_ctl_kernel(int *ctl) {
+  if (threadIdx.x < 2) ctl[threadIdx.x] = 0;
+}
+
 // Recomputes the listed (frame, pdf) pairs in plain fp32 with the reference's own
 // log-sum-exp (maximum first, then the sum); one wave per pair.
 __global__ void __launch_bounds__(256)
@@ -1764,10 +1768,14 @@ struct ScoreGraph {
 constexpr int kScoreGraphs = 4;         // per stream
 constexpr int kScoreGraphMaxFrames = 4096;
 
+constexpr size_t kCtlBlockBytes = 256;
+constexpr int kLaneFlagAt = kCtlBlockBytes / sizeof(int);
 struct StreamLane {
   hipStream_t stream = nullptr;
   uint64_t last_use = 0;
-  int *d_ctl = nullptr;  // {overflow count, range flag}
+  // [0] overflow count, [1] range flag: cleared at the start of every launch (gmm_clear_ctl_kernel);
+  // [kLaneFlagAt], in a 256-byte block of its own, a result was NaN/Inf: read and cleared by amlike_gmm_poll
+  int *d_ctl = nullptr;
   DeviceBuffer ws_part, ws_pad, ws_expand, ws_expand_safe, ws_fix, ws_gauss, ws_xplanes;
   ScoreGraph graphs[kScoreGraphs];
   void DropGraphs() {
@@ -1818,6 +1826,11 @@ struct amlike_gmm {
   AsyncSlot slots[kAsyncSlots];
   int32_t next_ticket = 0;
   bool use_graphs = false;  // AMLIKE_GMM_GRAPHS=1 at creation: small repeated calls replay a recorded graph
+  // Tuning aids, read from the environment once, when the handle is created:
+  // AMLIKE_GMM_FPB_TARGET (the frames-per-block figure the launch code aims at), AMLIKE_GMM_FPB
+  // (exactly this many frames per block), AMLIKE_GMM_SOLO (one block per compute unit).
+  int fpb_target = 4096, fpb_exact = 0;
+  bool solo = false;
   bool profile = false;  // amlike_gmm_profile_kernel: event pairs around the scoring kernel
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
   size_t kev_used = 0;
@@ -2249,8 +2262,8 @@ static int LaneFor(amlike_gmm *g, hipStream_t stream, StreamLane **out) {
     }
     lane->stream = stream;
     if (!lane->d_ctl) {
-      AMLIKE_HIP(hipMalloc(&lane->d_ctl, 2 * sizeof(int)));
-      AMLIKE_HIP(hipMemset(lane->d_ctl, 0, 2 * sizeof(int)));
+      AMLIKE_HIP(hipMalloc(&lane->d_ctl, 2 * kCtlBlockBytes));
+      AMLIKE_HIP(hipMemset(lane->d_ctl, 0, 2 * kCtlBlockBytes));
     }
   }
   lane->last_use = ++g->lane_clock;
@@ -2286,9 +2299,8 @@ static int LaunchScore(amlike_gmm *g, StreamLane *lane, const float *d_feats, in
   // operands (NT*D registers per lane) is amortised over many frame tiles, enough
   // blocks to keep every CU busy to the end, and equal shares (no short last chunk).
   const int cus = std::max(1, NumComputeUnits());
-  int target = 4096;  // (measured on 218.5 k frames: 2048 17.57, 3072 17.42, 4096 17.38, 6144 17.34, 8192 17.42 ms)
-  if (const char *e = getenv("AMLIKE_GMM_FPB_TARGET")) target = std::max(64, atoi(e));  // tuning aid: the chooser's aim
-  if (const char *e = getenv("AMLIKE_GMM_FPB")) target = std::max(32, atoi(e));  // tuning aid: exactly this
+  // (measured on 218.5 k frames: 2048 17.57, 3072 17.42, 4096 17.38, 6144 17.34, 8192 17.42 ms)
+  const int target = g->fpb_exact ? g->fpb_exact : g->fpb_target;
   int nby = std::max(1, (T + target - 1) / target);
   // Small batches: split the frames further so that every CU has a block.
   while (nbx * nby < cus && (T + nby - 1) / nby > 64) ++nby;
@@ -2296,7 +2308,7 @@ static int LaunchScore(amlike_gmm *g, StreamLane *lane, const float *d_feats, in
   // (frames per block + start-up); pick the split near the target that wastes least of
   // the last round.  The start-up (loading the operand registers) costs about as much as
   // 96 frames of scoring.
-  if (!getenv("AMLIKE_GMM_FPB")) {
+  if (!g->fpb_exact) {
     double best_cost = 0.0;
     int best = nby;
     for (int cand = std::max(1, nby - nby / 4); cand <= std::max(nby + nby / 3 + 1, 6); ++cand) {
@@ -2324,11 +2336,12 @@ static int LaunchScore(amlike_gmm *g, StreamLane *lane, const float *d_feats, in
   ar.nbx = nbx;
   ar.part_m = ar.part_s = nullptr;
   ar.part_ld = 0;
-  ar.flag = g->d_flag;
+  // non-finite results are reported per stream lane; the arena path has no lane and reports per handle
+  ar.flag = lane ? lane->d_ctl + kLaneFlagAt : g->d_flag;
   ar.ctl = lane ? lane->d_ctl : nullptr;
   if (arena) {  // the control words come from the arena too
     void *ctl = nullptr;
-    int rc = take(nullptr, 2 * sizeof(int), &ctl);
+    int rc = take(nullptr, kCtlBlockBytes, &ctl);
     if (rc != AMLIKE_OK) return rc;
     ar.ctl = static_cast<int *>(ctl);
   }
@@ -2365,7 +2378,7 @@ static int LaunchScore(amlike_gmm *g, StreamLane *lane, const float *d_feats, in
       AMLIKE_HIP(hipGetLastError());
       smem = 2 * FramesTilesPerBarrier(v.W, KS, parts) * tile_bytes + (size_t)v.W * v.NT * 32 * 4 +
              (size_t)v.W * DiffTailTableBytes(v.NT);
-      if (getenv("AMLIKE_GMM_SOLO") && *getenv("AMLIKE_GMM_SOLO")) smem = std::max<size_t>(smem, 100 * 1024);  // tuning aid: one block per CU
+      if (g->solo) smem = std::max<size_t>(smem, 100 * 1024);
       if (smem > 64 * 1024)
         AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -2381,7 +2394,7 @@ static int LaunchScore(amlike_gmm *g, StreamLane *lane, const float *d_feats, in
     if (g->num_splits > 0 && v.mode < 100) {
       hipLaunchKernelGGL(gmm_merge_parts_kernel, dim3((T + 255) / 256, g->num_splits), dim3(256), 0,
                          stream, g->d_splits, g->num_splits, a.part_m, a.part_s, a.part_ld, T, d_out,
-                         ldo, g->d_flag, ar.ctl, a.fix_list, a.fix_cap, guard);
+                         ldo, ar.flag, ar.ctl, a.fix_list, a.fix_cap, guard);
       AMLIKE_HIP(hipGetLastError());
     }
     return AMLIKE_OK;
@@ -2390,20 +2403,26 @@ static int LaunchScore(amlike_gmm *g, StreamLane *lane, const float *d_feats, in
     // Differenced pass, exact repair of the few pairs whose sum overflowed, and a full pass of
     // the wide-range kernel that runs only when the first pass could not be used (decided on
     // the device: features outside the fp16 range, or more overflows than the list holds).
-    const size_t cap = std::max<size_t>(4096, std::min<size_t>(arena ? (size_t)1 << 14 : (size_t)1 << 21,
-                                                              (size_t)T * g->num_pdfs / 256));
+    // (the same list length with and without an arena: which pairs are repaired exactly and when
+    // the wide-range kernel takes over must not depend on where the scratch memory comes from)
+    const size_t cap = std::max<size_t>(4096, std::min<size_t>((size_t)1 << 21, (size_t)T * g->num_pdfs / 256));
     void *fix = nullptr;
     int rc = take(lane ? &lane->ws_fix : nullptr, cap * sizeof(int2), &fix);
     if (rc != AMLIKE_OK) return rc;
     ar.fix_list = static_cast<int2 *>(fix);
     ar.fix_cap = (int)cap;
-    AMLIKE_HIP(hipMemsetAsync(ar.ctl, 0, 2 * sizeof(int), stream));
+    // Cleared by a kernel, not by hipMemsetAsync: recorded into a HIP graph, the fill node left the
+    // words as the previous replay's atomics had set them (every replay after the first then took
+    // the wide-range path; seen with 8-byte and 256-byte fills alike), while a kernel's stores are
+    // found by the next kernel's atomics and loads in eager launches and replays alike.
+    hipLaunchKernelGGL(gmm_clear_ctl_kernel, dim3(1), dim3(64), 0, stream, ar.ctl);
+    AMLIKE_HIP(hipGetLastError());
     rc = pass(v.kernel, v.expand, v.prec ? 2 : 3, g->d_apack, g->d_gcpack, lane ? &lane->ws_expand : nullptr, 1);
     if (rc != AMLIKE_OK) return rc;
     if (v.mode >= 300) return AMLIKE_OK;  // timing experiments: the main kernel alone
     hipLaunchKernelGGL(gmm_fix_kernel, dim3(1024), dim3(256), 0, stream, ar.ctl, ar.fix_list, ar.fix_cap,
                        g->d_gconsts, g->d_miv, g->d_iv, g->d_offsets, g->dim, d_feats, ld, d_out, ldo,
-                       g->d_flag);
+                       ar.flag);
     AMLIKE_HIP(hipGetLastError());
     rc = pass(v.safe_kernel, v.safe_expand, 3, g->d_apack_safe ? g->d_apack_safe : g->d_apack,
               g->d_gcpack_safe ? g->d_gcpack_safe : g->d_gcpack,
@@ -2540,6 +2559,9 @@ int amlike_gmm_create(const float *gconsts, const float *means_invvars, const fl
   g->dim = dim;
   g->device = CurrentDevice();
   if (const char *e = getenv("AMLIKE_GMM_GRAPHS")) g->use_graphs = e[0] == '1';
+  if (const char *e = getenv("AMLIKE_GMM_FPB_TARGET")) g->fpb_target = std::max(64, atoi(e));
+  if (const char *e = getenv("AMLIKE_GMM_FPB")) g->fpb_exact = std::max(32, atoi(e));
+  if (const char *e = getenv("AMLIKE_GMM_SOLO")) g->solo = e[0] != 0;
   g->variant = v;
   g->pdf_offsets.assign(pdf_offsets, pdf_offsets + num_pdfs + 1);
   int rc = v ? PackModel(g, gconsts, means_invvars, inv_vars, pdf_offsets) : AMLIKE_OK;
@@ -2652,7 +2674,7 @@ int amlike_gmm_score_dev(amlike_gmm_t *g, const float *d_feats, int32_t T, int32
         const int rn = std::min(launch_rows, tn - r0);
         hipLaunchKernelGGL(gmm_pruned_lse_kernel, dim3((g->num_pdfs + 255) / 256, rn), dim3(256), 0, st,
                            scores + (size_t)r0 * G, G, g->d_offsets, g->num_pdfs, rn, log_sum_exp_prune,
-                           d_out + (size_t)(t0 + r0) * ldo, ldo, g->d_flag);
+                           d_out + (size_t)(t0 + r0) * ldo, ldo, lane->d_ctl + kLaneFlagAt);
         AMLIKE_HIP(hipGetLastError());
       }
     }
@@ -2742,10 +2764,23 @@ int amlike_gmm_poll(amlike_gmm_t *g, void *stream) {
   if (int brc = BindHandle(g)) return brc;
   if (!g) return AMLIKE_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int flag = 0;
-  AMLIKE_HIP(hipMemcpyAsync(&flag, g->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  // The flag of this stream's lane (launches of amlike_gmm_score_dev / _gauss_loglikes_dev on it)
+  // and the handle's own (amlike_gmm_score_dev_noalloc, which has no lane).
+  int *lane_flag = nullptr;
+  {
+    std::lock_guard<std::mutex> lane_lock(g->lane_mu);
+    for (auto &l : g->lanes)
+      if (l->stream == st && l->d_ctl) lane_flag = l->d_ctl + kLaneFlagAt;
+  }
+  int flags[2] = {0, 0};
+  AMLIKE_HIP(hipMemcpyAsync(&flags[0], g->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
   AMLIKE_HIP(hipMemsetAsync(g->d_flag, 0, sizeof(int), st));
+  if (lane_flag) {
+    AMLIKE_HIP(hipMemcpyAsync(&flags[1], lane_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    AMLIKE_HIP(hipMemsetAsync(lane_flag, 0, sizeof(int), st));
+  }
   AMLIKE_HIP(hipStreamSynchronize(st));
+  const int flag = flags[0] | flags[1];
   if (flag) {
     SetError("Invalid answer (overflow or invalid variances/features?)");
     return AMLIKE_ENONFINITE;
@@ -2881,8 +2916,18 @@ int amlike_gmm_score_submit(amlike_gmm_t *g, const float *feats, int32_t T, int3
                                 (size_t)g->dim * sizeof(float), T, hipMemcpyHostToDevice, g->stream));
   rc = amlike_gmm_score_dev(g, df, T, dld, feat_dim, log_sum_exp_prune, dout, P, g->stream);
   if (rc != AMLIKE_OK) return rc;
-  AMLIKE_HIP(hipMemcpyAsync(s->h_flag, g->d_flag, sizeof(int), hipMemcpyDeviceToHost, g->stream));
-  AMLIKE_HIP(hipMemsetAsync(g->d_flag, 0, sizeof(int), g->stream));
+  {  // the flag of the lane amlike_gmm_score_dev has just used for the handle's stream
+    int *lane_flag = nullptr;
+    std::lock_guard<std::mutex> lane_lock(g->lane_mu);
+    for (auto &l : g->lanes)
+      if (l->stream == g->stream && l->d_ctl) lane_flag = l->d_ctl + kLaneFlagAt;
+    if (!lane_flag) {
+      SetError("amlike_gmm_score_submit: no working memory for the handle's stream");
+      return AMLIKE_EINVAL;
+    }
+    AMLIKE_HIP(hipMemcpyAsync(s->h_flag, lane_flag, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    AMLIKE_HIP(hipMemsetAsync(lane_flag, 0, sizeof(int), g->stream));
+  }
   AMLIKE_HIP(hipEventRecord(s->computed, g->stream));
   AMLIKE_HIP(hipStreamWaitEvent(g->copy_stream, s->computed, 0));
   if (ldo == P)

@@ -11,13 +11,14 @@
 #include <cstring>
 #include <stdexcept>
 #include <thread>
+#include <vector>
+#include <algorithm>
 
 namespace kaldi_amd {
-namespace {
 
-// RCCL is loaded when a reduction is asked for, not at program start: a run of one process
+// RCCL is loaded only when a job of several processes asks for its totals: a run of one process
 // does not pay for it.
-struct Rccl {
+struct JobTotals::Rccl {
   void *handle = nullptr;
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
@@ -48,6 +49,8 @@ struct Rccl {
       throw std::runtime_error(std::string("job totals: ") + what + ": " + GetErrorString(r));
   }
 };
+
+namespace {
 
 void CheckHip(hipError_t e, const char *what) {
   if (e != hipSuccess) throw std::runtime_error(std::string("job totals: ") + what + ": " + hipGetErrorString(e));
@@ -86,44 +89,65 @@ void AwaitId(const std::string &path, ncclUniqueId *id, int timeout_s) {
 
 }  // namespace
 
-void AllReduceJobTotals(const JobTotalsOptions &opts, int device, long long *counts, int n, int timeout_s) {
-  if (opts.num_procs < 1 || opts.proc_id < 0 || opts.proc_id >= opts.num_procs)
-    throw std::runtime_error("job totals: --proc-id must lie in [0, --num-procs)");
-  if (opts.rendezvous.empty()) throw std::runtime_error("job totals: --rendezvous is needed with --num-procs");
+JobTotals::JobTotals(const JobTotalsOptions &opts, int device) : device_(device) {
   static_assert(sizeof(long long) == 8, "counts travel as 64-bit integers");
-  Rccl rccl;
-  CheckHip(hipSetDevice(device), "hipSetDevice");
-  ncclUniqueId id;
-  std::memset(&id, 0, sizeof(id));
-  if (opts.proc_id == 0) {
-    rccl.Check(rccl.GetUniqueId(&id), "ncclGetUniqueId");
-    PublishId(opts.rendezvous, id);
-  } else {
-    AwaitId(opts.rendezvous, &id, timeout_s);
+  try {
+    if (opts.num_procs < 1 || opts.proc_id < 0 || opts.proc_id >= opts.num_procs)
+      throw std::runtime_error("job totals: --proc-id must lie in [0, --num-procs)");
+    if (opts.rendezvous.empty()) throw std::runtime_error("job totals: --rendezvous is needed with --num-procs");
+    rccl_ = new Rccl;
+    CheckHip(hipSetDevice(device), "hipSetDevice");
+    ncclUniqueId id;
+    std::memset(&id, 0, sizeof(id));
+    if (opts.proc_id == 0) {
+      rccl_->Check(rccl_->GetUniqueId(&id), "ncclGetUniqueId");
+      PublishId(opts.rendezvous, id);
+    } else {
+      AwaitId(opts.rendezvous, &id, opts.rendezvous_timeout);
+    }
+    ncclComm_t comm = nullptr;
+    const ncclResult_t joined = rccl_->CommInitRank(&comm, opts.num_procs, id, opts.proc_id);
+    if (opts.proc_id == 0) unlink(opts.rendezvous.c_str());  // every process has read it by now, or the job failed
+    rccl_->Check(joined, "ncclCommInitRank");
+    comm_ = comm;
+  } catch (const std::exception &e) {
+    error_ = e.what();
+    comm_ = nullptr;
   }
-  ncclComm_t comm = nullptr;
-  const ncclResult_t joined = rccl.CommInitRank(&comm, opts.num_procs, id, opts.proc_id);
-  if (opts.proc_id == 0) unlink(opts.rendezvous.c_str());  // every process has read it by now, or the job failed
-  rccl.Check(joined, "ncclCommInitRank");
+}
+
+JobTotals::~JobTotals() {
+  if (comm_ && rccl_) (void)rccl_->CommDestroy(static_cast<ncclComm_t>(comm_));
+  delete rccl_;
+}
+
+bool JobTotals::AllReduce(long long *counts, int n) {
+  if (!comm_) {
+    if (error_.empty()) error_ = "job totals: this process has not joined the job";
+    return false;
+  }
   long long *d_counts = nullptr;
   hipStream_t stream = nullptr;
+  bool ok = true;
   try {
+    CheckHip(hipSetDevice(device_), "hipSetDevice");
     CheckHip(hipMalloc(reinterpret_cast<void **>(&d_counts), sizeof(long long) * n), "hipMalloc");
     CheckHip(hipStreamCreate(&stream), "hipStreamCreate");
     CheckHip(hipMemcpyAsync(d_counts, counts, sizeof(long long) * n, hipMemcpyHostToDevice, stream), "copy up");
-    rccl.Check(rccl.AllReduce(d_counts, d_counts, static_cast<size_t>(n), ncclInt64, ncclSum, comm, stream),
-               "ncclAllReduce");
-    CheckHip(hipMemcpyAsync(counts, d_counts, sizeof(long long) * n, hipMemcpyDeviceToHost, stream), "copy down");
+    rccl_->Check(rccl_->AllReduce(d_counts, d_counts, static_cast<size_t>(n), ncclInt64, ncclSum,
+                                  static_cast<ncclComm_t>(comm_), stream),
+                 "ncclAllReduce");
+    std::vector<long long> sums(n);
+    CheckHip(hipMemcpyAsync(sums.data(), d_counts, sizeof(long long) * n, hipMemcpyDeviceToHost, stream), "copy down");
     CheckHip(hipStreamSynchronize(stream), "hipStreamSynchronize");
-  } catch (...) {
-    if (stream) (void)hipStreamDestroy(stream);
-    if (d_counts) (void)hipFree(d_counts);
-    (void)rccl.CommDestroy(comm);
-    throw;
+    std::copy(sums.begin(), sums.end(), counts);  // the caller's own counts stay intact on failure
+  } catch (const std::exception &e) {
+    error_ = e.what();
+    ok = false;
   }
-  (void)hipStreamDestroy(stream);
-  (void)hipFree(d_counts);
-  rccl.Check(rccl.CommDestroy(comm), "ncclCommDestroy");
+  if (stream) (void)hipStreamDestroy(stream);
+  if (d_counts) (void)hipFree(d_counts);
+  return ok;
 }
 
 }  // namespace kaldi_amd

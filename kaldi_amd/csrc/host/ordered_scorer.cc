@@ -45,13 +45,19 @@ OrderedScorer::~OrderedScorer() {
 void OrderedScorer::Publish(const std::vector<ScoreJob *> &window) {
   {
     std::unique_lock<std::mutex> lock(mu_);
-    // taken from the back: longest first, the earlier of two equally long ones first
+    // Taken from the back: what is left of an older window before anything of this one (the
+    // writer commits in input order and is waiting for the older jobs); within a window the
+    // longest first, the earlier of two equally long ones first.
+    ++windows_published_;
     for (auto it = window.rbegin(); it != window.rend(); ++it) {
       (*it)->done = false;
+      (*it)->window = windows_published_;
       queue_.push_back(*it);
     }
-    std::stable_sort(queue_.begin(), queue_.end(),
-                     [](const ScoreJob *a, const ScoreJob *b) { return a->TotalRows() < b->TotalRows(); });
+    std::stable_sort(queue_.begin(), queue_.end(), [](const ScoreJob *a, const ScoreJob *b) {
+      if (a->window != b->window) return a->window > b->window;
+      return a->TotalRows() < b->TotalRows();
+    });
   }
   work_cv_.notify_all();
 }
@@ -136,7 +142,8 @@ void OrderedScorer::Run(int32 index) {
   };
   for (;;) {
     ScoreJob *job = nullptr;
-    if (!pipe->Full()) job = Take(/*block=*/in_flight.empty() && retry.empty());
+    // A job waiting to be scored again holds up the writer: nothing new is taken until it is done.
+    if (!pipe->Full() && retry.empty()) job = Take(/*block=*/in_flight.empty());
     if (job) {
       job->worker = index;
       const size_t n = job->keys.size();

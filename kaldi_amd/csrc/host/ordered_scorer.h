@@ -41,6 +41,7 @@ struct ScoreJob {
   std::vector<std::string> errors;   // per utterance: empty = scored
   int32 worker = -1;                 // which worker scored it
   bool done = false;
+  long long window = 0;              // which Publish() call handed it over
   int32 TotalRows() const { return feats.NumRows(); }
 };
 
@@ -78,7 +79,8 @@ class OrderedScorer {
   std::vector<std::unique_ptr<Worker>> workers_;
   std::mutex mu_;
   std::condition_variable work_cv_, done_cv_, start_cv_;
-  std::vector<ScoreJob *> queue_;  // longest last (taken from the back)
+  std::vector<ScoreJob *> queue_;  // taken from the back: oldest window last, within a window longest last
+  long long windows_published_ = 0;
   bool stop_ = false;
 };
 

@@ -643,7 +643,7 @@ template <int GS, int PREC>
 __global__ void __launch_bounds__(256, 2)
     nnet_gemm_pnorm_kernel(const uint4 *__restrict__ Xp, size_t xplane, const uint4 *__restrict__ Wp,
                            int Kp, float *__restrict__ Y, int ldy, int M, int Npad, int G,
-                           const int *flag, int gmode) {
+                           const int *flag, int gmode, int xcd_order) {
   static_assert(80 % GS == 0, "a half-lane holds 80 units");
   if (nnet_guard_skips(flag, gmode)) return;
   constexpr int NPL = PREC ? 2 : 3, NPROD = PREC ? 3 : 6;
@@ -651,7 +651,20 @@ __global__ void __launch_bounds__(256, 2)
   __shared__ __attribute__((aligned(16))) uint4 s_w[2][NPL][5][64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int li = lane & 31, h = lane >> 5;
-  const int u0 = blockIdx.x * 160, m0 = blockIdx.y * 128;
+  // Which (unit block, frame block) this workgroup computes.  Workgroups are dealt round-robin
+  // over the 8 XCDs in launch order; with xcd_order each XCD gets a contiguous run of the
+  // (frame block, unit block) sequence, unit block fastest, so that the gridDim.x workgroups
+  // that read one 128-frame panel of X run on one XCD at about the same time: the panel comes
+  // from memory once and from that XCD's L2 afterwards (W, 1-3 MB, lives in every L2).
+  int bxu = blockIdx.x, bym = blockIdx.y;
+  if (xcd_order) {
+    const int total = gridDim.x * gridDim.y, L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = L & 7;
+    const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    bym = Lp / gridDim.x;
+    bxu = Lp - bym * gridDim.x;
+  }
+  const int u0 = bxu * 160, m0 = bym * 128;
   const int kp8 = Kp >> 3, nk = Kp >> 4;
   const size_t wplane = (size_t)Npad * kp8;
   // staging: wave w copies X row block w and W row blocks w and w + 4 (w + 4 exists for w = 0)
@@ -724,11 +737,11 @@ __global__ void __launch_bounds__(256, 2)
     __syncthreads();
   }
   // Epilogue: this lane is frame m0 + 32 w + li; its 80 values (tile a, register r) are slots
-  // a * 16 + r = GS-sized groups number (80 / GS) * (2 * blockIdx.x + h) + slot / GS.
+  // a * 16 + r = GS-sized groups number (80 / GS) * (2 * unit block + h) + slot / GS.
   const int m = m0 + w * 32 + li;
   if (m >= M) return;
   float *o = Y + (size_t)m * ldy;
-  const int g0 = (80 / GS) * (2 * blockIdx.x + h);
+  const int g0 = (80 / GS) * (2 * bxu + h);
 #pragma unroll
   for (int gl = 0; gl < 80 / GS; ++gl) {
     float ss = 0.0f;
@@ -1653,6 +1666,7 @@ struct amlike_nnet {
   int num_priors = 0;
   bool gemm_f32 = false;  // AMLIKE_NNET_GEMM=f32: the exact-fp32 MFMA GEMM (A/B check of the bf16x3 one)
   bool gemm_inline_split = false;  // AMLIKE_NNET_GEMM=inline: bf16x3 GEMM that splits X in its k-loop
+  int pnorm_xcd_order = 1;  // AMLIKE_NNET_PNORM_XCD=0: launch-order block mapping in the affine + p-norm kernel (A/B aid)
   float *d_log_priors = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // submit / wait: the copies out, behind the kernels
@@ -2054,7 +2068,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
 #define AMLIKE_PNORM_LAUNCH(GS, PREC, XPL, WPN, GMODE)                                            \
   hipLaunchKernelGGL((nnet_gemm_pnorm_kernel<GS, PREC>), fgrid, dim3(256), 0, st,                \
                      reinterpret_cast<const uint4 *>(XPL), pstride / 8, WPN, s.Kpn, pdst, pld,    \
-                     (int)cur_rows, s.Npad, G, flag, GMODE)
+                     (int)cur_rows, s.Npad, G, flag, GMODE, n->pnorm_xcd_order)
       auto fused = [&](int prec, const unsigned short *xpl, const uint4 *wpn, int gmode) {
         if (s.fuse_gs == 10 && prec) AMLIKE_PNORM_LAUNCH(10, 1, xpl, wpn, gmode);
         else if (s.fuse_gs == 10) AMLIKE_PNORM_LAUNCH(10, 0, xpl, wpn, gmode);
@@ -2301,6 +2315,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
     n->gemm_f32 = strcmp(e, "f32") == 0;
     n->gemm_inline_split = strcmp(e, "inline") == 0;
   }
+  if (const char *e = getenv("AMLIKE_NNET_PNORM_XCD")) n->pnorm_xcd_order = e[0] != '0';
   n->input_dim = comps[0].input_dim;
   int dim = comps[0].input_dim;
   int rc = AMLIKE_OK;

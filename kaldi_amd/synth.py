@@ -122,3 +122,56 @@ def make_pnorm_nnet(input_dim=40, left=4, right=4, hidden=2000, pnorm_out=200, n
     priors = rng.dirichlet(np.full(num_pdfs, 2.0)).astype(np.float32)
     priors = np.maximum(priors, 1e-8).astype(np.float32)
     return comps, priors
+
+
+def nnet_fullsize_utterances(kind="plain", input_dim=40, seed=781):
+    """The utterances of the full-size nnet2 parity fixtures (tests/golden/make_golden_nnet_swbd.py).
+
+    kind "plain": 10 240 frames in utterances of 1 ... 1500 frames (edge padding repeats the first
+    and last frame of EACH utterance, nnet2/nnet-compute.cc:74-86), unit-variance input;
+    "x100": the same distribution times 100 (first-layer operands far from 1, still inside fp16);
+    "huge": values beyond 32768 in a few places (an fp16 operand cannot hold them);
+    "peaky": 2 048 frames for make_peaky_nnet."""
+    rng = np.random.default_rng(seed + {"plain": 0, "x100": 1, "huge": 2, "peaky": 3}[kind])
+    if kind == "plain":
+        lens = [1, 2, 5, 9, 33, 130, 300, 777, 1500, 1024, 911, 640, 1203, 1377, 999, 1329]
+    elif kind == "peaky":
+        lens = [3, 700, 1345]
+    else:
+        lens = [7, 250, 511]
+    utts = [rng.normal(size=(n, input_dim)).astype(np.float32) for n in lens]
+    if kind == "x100":
+        utts = [u * np.float32(100.0) for u in utts]
+    if kind == "huge":
+        for u in utts:
+            for _ in range(1 + len(u) // 100):
+                u[rng.integers(len(u)), rng.integers(input_dim)] = np.float32(rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(4.6, 6.0))
+    return utts
+
+
+def make_peaky_nnet(scale=100.0, seed=780):
+    """make_pnorm_nnet with an output layer whose answer turns on the input.  P-norm outputs are all
+    positive, so a normalised hidden vector is mostly one fixed vector plus a small input-dependent
+    part, and with N(0, 1/sqrt(in)) weights one pdf wins every frame.  Here the rows of the last
+    affine layer are made orthogonal to the mean hidden vector (estimated on 512 random inputs),
+    scaled up, and the bias removed: the best pdf changes from frame to frame.  Every seventh pdf
+    gets a bias of -80, which puts its posterior under the 1e-20 floor of
+    nnet2/nnet-component.cc:917 on every frame."""
+    comps, priors = make_pnorm_nnet(seed=seed)
+    rng = np.random.default_rng(seed + 1000)
+    h = rng.normal(size=(512, comps[1]["linear"].shape[1]))
+    for c in comps[1:-2]:
+        if "linear" in c:
+            h = h @ c["linear"].astype(np.float64).T + c["bias"].astype(np.float64)
+        elif c["type"] == "PnormComponent":
+            h = np.sqrt((h.reshape(len(h), c["output_dim"], -1) ** 2).sum(2))
+        elif c["type"] == "NormalizeComponent":
+            h = h / np.sqrt((h ** 2).mean(1, keepdims=True))
+    mean = h.mean(0)
+    mean /= np.linalg.norm(mean)
+    last = comps[-2]
+    w = last["linear"].astype(np.float64)
+    last["linear"] = ((w - np.outer(w @ mean, mean)) * scale).astype(np.float32)
+    last["bias"] = np.zeros_like(last["bias"])
+    last["bias"][::7] = -80.0
+    return comps, priors

@@ -140,14 +140,18 @@ def test_gmm_compute_likes_several_workers_same_archive(many_utts):
 def test_gmm_compute_likes_a_bad_utterance_costs_only_itself(many_utts, tmp_path):
     """Non-finite features in one utterance of a batch: its batch-mates are scored again on their
     own and written, the bad one is reported and counted, the run goes on (the reference's drivers
-    count an utterance that fails and continue, gmmbin/gmm-latgen-faster.cc:118-122)."""
+    count an utterance that fails and continue, gmmbin/gmm-latgen-faster.cc:118-122), and the exit
+    status is non-zero, as the reference's is."""
     d, model, items = many_utts
     bad = [(k, f.copy()) for k, f in items[:12] if f.shape[0]]
     bad[4][1][3, 5] = np.nan
     kio.write_ark(str(tmp_path / "feats.ark"), bad)
     out = str(tmp_path / "likes.ark")
     p = run("gmm-compute-likes", "--devices=0,0", "--frames-per-batch=1500", str(d / "final.mdl"),
-            "ark:" + str(tmp_path / "feats.ark"), "ark:" + out)
+            "ark:" + str(tmp_path / "feats.ark"), "ark:" + out, ok=False)
+    # the exit status tells the calling script that keys are missing (the reference's run ends
+    # with -1 at the first such utterance, gmmbin/gmm-compute-likes.cc:85-88)
+    assert p.returncode != 0
     warning = [l for l in p.stderr.split(b"\n") if b"utterance " + bad[4][0].encode() + b" failed:" in l]
     assert len(warning) == 1 and b"Invalid answer" in warning[0], p.stderr
     assert b"computed likelihoods for %d utterances, failed for 1" % (len(bad) - 1) in p.stderr
@@ -173,13 +177,20 @@ def test_job_totals_go_through_rccl(many_utts, tmp_path):
     run("gmm-compute-likes", "--frames-per-batch=900", str(d / "final.mdl"), "ark:" + str(d / "feats.ark"),
         "ark:" + str(tmp_path / "plain.ark"))
     assert open(str(tmp_path / "likes.ark"), "rb").read() == open(str(tmp_path / "plain.ark"), "rb").read()
-    # bad arguments are refused with a message, after the scoring, where the reduction would start
+    # bad arguments are refused with a message, before anything is read
     q = run("gmm-compute-likes", "--num-procs=2", "--proc-id=2", "--rendezvous=" + rdv, str(d / "final.mdl"),
             "ark:" + str(d / "feats.ark"), "ark:" + str(tmp_path / "x.ark"), ok=False)
     assert q.returncode != 0 and b"--proc-id must lie in" in q.stderr
     q = run("gmm-compute-likes", "--num-procs=2", "--proc-id=1", str(d / "final.mdl"),
             "ark:" + str(d / "feats.ark"), "ark:" + str(tmp_path / "x.ark"), ok=False)
     assert q.returncode != 0 and b"--rendezvous is needed" in q.stderr
+    # a process whose job never forms (process 0 does not show up) warns, scores its slice, and
+    # keeps the exit status of its scoring run
+    q = run("gmm-compute-likes", "--num-procs=2", "--proc-id=1", "--rendezvous=" + rdv + ".never",
+            "--rendezvous-timeout=1", "--frames-per-batch=900", str(d / "final.mdl"),
+            "ark:" + str(d / "feats.ark"), "ark:" + str(tmp_path / "alone.ark"))
+    assert b"WARNING" in q.stderr and b"did not publish" in q.stderr and b"all 2 processes" not in q.stderr
+    assert open(str(tmp_path / "alone.ark"), "rb").read() == open(str(tmp_path / "plain.ark"), "rb").read()
 
 
 def test_num_gpus_beyond_the_visible_devices_is_refused(many_utts, tmp_path):

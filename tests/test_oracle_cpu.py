@@ -260,3 +260,23 @@ def test_oracle_vs_full_size_reference_summaries(name, cfg, mseed, fseed, rows):
     assert np.abs(got.astype(np.float64).sum(1) - g["rowsum"][pick]).max() / P <= 1e-5
     near_tie = g["best"][pick] - g["second"][pick] < 1e-4
     assert ((got.argmax(1) == g["argmax"][pick]) | near_tie).all()
+
+
+@pytest.mark.parametrize("fixture,kind,utts", [("nnet_swbd_10k", "plain", 6), ("nnet_swbd_10k", "huge", 2),
+                                               ("nnet_swbd_peaky_2k", "peaky", 2)])
+def test_nnet_oracle_vs_full_size_reference_summaries(fixture, kind, utts):
+    """The nnet2 restatement on the first utterances of the full-size fixtures (per-frame summaries
+    of what the real reference computed for the swbd p-norm shape,
+    tests/golden/make_golden_nnet_swbd.py)."""
+    g = np.load(gpath(fixture + ".npz"))
+    comps, priors = synth.make_peaky_nnet() if kind == "peaky" else synth.make_pnorm_nnet(seed=780)
+    us = synth.nnet_fullsize_utterances(kind)[:utts]
+    got = np.concatenate([oracle.nnet_compute(comps, priors, u, True, 2, 1.0) for u in us])
+    n = len(got)
+    r = np.arange(n)
+    assert np.abs(got[r, g[kind + "_argmax"][:n]] - g[kind + "_best"][:n]).max() <= 2e-4
+    assert np.abs(got[:, g["pdf_cols"]] - g[kind + "_cols"][:n]).max() <= 2e-4
+    assert np.abs(got.astype(np.float64).sum(1) - g[kind + "_rowsum"][:n]).max() / got.shape[1] <= 2e-5
+    post = got + np.log(priors)[None, :]
+    assert (post.argmax(1) == g[kind + "_post_argmax"][:n]).all()
+    assert (got.argmax(1) == g[kind + "_argmax"][:n]).all()
