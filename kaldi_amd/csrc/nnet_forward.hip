@@ -1114,6 +1114,13 @@ __device__ __forceinline__ void lds_hidden_write_at(unsigned addr, const f32x4 &
   asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFFSET) : "memory");
 #endif
 }
+// Waits until at most N of the wave's LDS reads are outstanding; a and b are ready afterwards.
+template <int N>
+__device__ __forceinline__ void lds_hidden_wait_but(f32x4 &a, f32x4 &b) {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+#endif
+}
 __device__ __forceinline__ void lds_hidden_wait1(f32x4 &a) {
 #if __HIP_DEVICE_COMPILE__
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a));
@@ -1140,6 +1147,17 @@ __device__ __forceinline__ void mfma_f16_asm(f32x16 &acc, const bf16x8_t &a, con
     if constexpr (AFTER_INIT) asm volatile("s_nop 4\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
   }
+#endif
+}
+// The same with the accumulator in the ordinary registers and the b operand in the accumulation
+// half: vector instructions then read the results where they lie.  (A v_accvgpr_read placed
+// between matrix instructions was measured at 15-20 cycles: 32 of them per tile cost a fifth of
+// the row-stationary affine + p-norm kernel's time.)  FIRST: the chain starts from zero.
+template <bool FIRST, class AFrag>
+__device__ __forceinline__ void mfma_f16_asm_vacc(f32x16 &acc, const AFrag &a, const bf16x8_t &b) {
+#if __HIP_DEVICE_COMPILE__
+  if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));  // (the result may not share registers with a or b)
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
 #endif
 }
 // Covers the distance a vector instruction must keep behind a matrix instruction whose result it reads.
@@ -1549,6 +1567,281 @@ __global__ void __launch_bounds__(256, 1)
   }
 }
 
+// Affine + p-norm (p = 2, groups of 10) with the ROWS stationary: the hidden layers of the p-norm
+// nets behind a NormalizeComponent (fp16x2 operands, k <= 207 plus the bias column).  Same
+// skeleton as nnet_out_softmax_kernel -- a wave keeps the operand fragments of its FT x 32 rows
+// of X in registers for the whole job, the W tiles of 32 units stream global -> LDS ring ->
+// fragments, one wave per SIMD, the vector work on tile t - 1 placed between the matrix
+// instructions of tile t -- with one sweep over the units and this vector work: every value is
+// squared and added to the sum of its p-norm group.  The host orders the rows of W
+// (BuildPnormRowsWeights) so that, of the 16 values a lane holds of any tile, value r belongs to
+// group r % 8 of the 8 groups its half-wave owns in the current run of 5 tiles ("super-tile": 160
+// units = 16 groups): the group sums are 8 registers per frame tile whatever the tile, and after
+// every fifth tile they are complete: square root, 32 bytes per lane to Y, start over.
+// Against nnet_gemm_pnorm_kernel (a block per 160 units x 128 rows, X and W both staged per
+// k-step behind a barrier): X is read once per job instead of once per unit block, there is one
+// barrier per 78 matrix instructions instead of one per 15, and no wave waits for its own X.
+// X: planes [2][Kp/8][M] as the other kernels read them, the bias column's 1.0 included.
+// W: [2][Kp/8][Npad] in the row order above, Npad a multiple of 160.  Y: [M x ldy], G groups.
+#ifndef AMLIKE_ROWS_ABL
+#define AMLIKE_ROWS_ABL 0
+#endif
+#ifdef AMLIKE_ROWS_STAMPS  // diagnostic build: clock ticks per part of a step, waves 0 and 4 of block 0
+__device__ unsigned long long g_rows_stamps[16];
+#endif
+struct RowJobs {
+  int nbig;   // jobs of 256 rows (blocks 0 .. nbig-1)
+  int small;  // rows per remaining job (a multiple of 32, at most 256); their rows follow the big jobs'
+};
+
+__host__ __device__ constexpr int PnormRowsRing(int KS) {
+  const int tile = 2 * 2 * KS * 32 * 16;
+  return 160 * 1024 / tile >= 6 ? 5 : 160 * 1024 / tile - 1;
+}
+
+template <int KS>
+__global__ void __launch_bounds__(512, 2)
+    nnet_pnorm_rows_kernel(const uint4 *__restrict__ Xp, size_t xplane, const uint4 *__restrict__ Wp,
+                           size_t wplane, int Npad, float *__restrict__ Y, int ldy, int M, int G,
+                           RowJobs jobs) {
+  constexpr int NPL = 2, NPROD = 3, NW = 8;
+  constexpr int kTileU4 = NPL * 2 * KS * 32;  // uint4 per staged W tile: [plane][octet][32 units]
+  constexpr int kRing = PnormRowsRing(KS), kLead = kRing - 1;  // tile seq + kLead is requested in step seq
+  static_assert(kRing >= 4, "the W ring needs four tiles");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
+  uint4 *s_w = reinterpret_cast<uint4 *>(smem_r);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  int row0, nrows;
+  const int b = blockIdx.x;
+  if (b < jobs.nbig) {
+    row0 = b * 256;
+    nrows = 256;
+  } else {
+    row0 = jobs.nbig * 256 + (b - jobs.nbig) * jobs.small;
+    nrows = min(jobs.small, M - row0);
+  }
+  if (nrows <= 0) return;
+  const int ntile = Npad >> 5;  // a multiple of 5
+
+  // W tile seq travels global -> LDS ring slot seq % kRing in pieces of 1 KiB (64 lanes x 16 bytes:
+  // two octets of one plane for 32 units), dealt round-robin to the 8 waves.  Every wave issues
+  // exactly kMine loads per tile (a wave short of a piece repeats the last one), so "all but the
+  // newest n * kMine vector-memory instructions have finished" means: every tile but the n
+  // requested last has landed.  (The stores of finished groups count too, and they are older
+  // than some of those loads: the wait is then for a little more than it names, never less.)
+  // A piece's source is Wp + 512 bytes x tile + a per-lane offset that does not change from tile
+  // to tile, kept in a register per piece; its place in a ring slot is wave-uniform.
+  constexpr int kPieces = NPL * KS, kMine = (kPieces + NW - 1) / NW;
+  const int rot = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 7u) % (unsigned)(NW * kMine)));
+  unsigned piece_off[kMine];  // bytes from Wp + 512 tile
+  int piece_at[kMine];        // uint4 index inside a ring slot
+#pragma unroll
+  for (int i = 0; i < kMine; ++i) {
+    const int piece = min((w + NW * i + rot) % (NW * kMine), kPieces - 1);
+    const int q = piece / KS, op = piece - q * KS;  // plane, octet pair
+    piece_off[i] = (unsigned)(((size_t)q * wplane + (size_t)(2 * op + h) * Npad + li) * 16);
+    piece_at[i] = __builtin_amdgcn_readfirstlane(piece * 64);
+  }
+  auto request = [&](int seq) __attribute__((always_inline)) {
+    const char *src0 = reinterpret_cast<const char *>(Wp) + (size_t)(seq % ntile) * 512;
+    uint4 *dst = s_w + (seq % kRing) * kTileU4;
+#pragma unroll
+    for (int i = 0; i < kMine; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + piece_off[i]),
+                                       (__attribute__((address_space(3))) void *)(dst + piece_at[i]), 16, 0, 0);
+  };
+
+  constexpr int NMF = KS * NPROD;  // matrix instructions per W tile
+  constexpr int NE = 16;           // values of a finished tile per lane
+  constexpr int kSkip = 3;         // matrix instructions of a step issued before the previous tile's values are read
+  const int rl = w * 32 + li;      // this lane's row within the job
+  bf16x8_t xf[KS][NPL];
+  {
+    const size_t r = (size_t)min(row0 + rl, M - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+        xf[ks][q] = __builtin_bit_cast(bf16x8_t, Xp[(size_t)q * xplane + (size_t)(2 * ks + h) * M + r]);
+  }
+  float ss[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) ss[g] = 0.0f;
+  static_for<kLead>([&](auto t) __attribute__((always_inline)) { request(decltype(t)::value); });
+
+  // A tile's values are the sums of two accumulators: x takes the products of the operands' high
+  // parts, y the two cross products (small terms among themselves).  Two chains, because a matrix
+  // instruction that continues the chain of the one just before it issues about 9 cycles late
+  // (41 instead of 32 cycles per instruction measured for a wave alone on its SIMD).
+  struct TileAcc {
+    f32x16 x, y;
+  };
+  // the vector work on value r of a finished tile
+  auto square_unit = [&](const TileAcc &acc, auto r_tag) __attribute__((always_inline)) {
+    constexpr int r = decltype(r_tag)::value;
+    const float v = acc.x[r] + acc.y[r];
+    ss[r & 7] = fmaf(v, v, ss[r & 7]);
+    pin_order(ss[r & 7]);
+  };
+  // the groups of super-tile `sup` are complete: this lane's 8 (half h) of its row
+  auto finish_groups = [&](int sup) __attribute__((always_inline)) {
+    const int g0 = 16 * sup + 8 * h;
+    float4 lo = make_float4(sqrtf(ss[0]), sqrtf(ss[1]), sqrtf(ss[2]), sqrtf(ss[3]));
+    float4 hi = make_float4(sqrtf(ss[4]), sqrtf(ss[5]), sqrtf(ss[6]), sqrtf(ss[7]));
+    if (rl < nrows) {
+      float *o = Y + (size_t)(row0 + rl) * ldy + g0;
+      if (g0 + 8 <= G) {
+        *reinterpret_cast<float4 *>(o) = lo;
+        *reinterpret_cast<float4 *>(o + 4) = hi;
+      } else {
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+          if (g0 + g < G) o[g] = v[g];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) ss[g] = 0.0f;
+  };
+
+  constexpr int kAhead = 2;
+  static_assert(KS % 3 == 1, "the register slots below assume KS = 3 n + 1");
+  // Fragments of W, read from LDS kAhead k-steps before their use, as reads the compiler does not
+  // see, with counted waits: left to the compiler, every third k-step waited for ALL reads in
+  // flight, the ones just issued included.  Past the end of the stream the reads go on (to a
+  // ring slot that holds some older tile; the values are not used): the count of reads in
+  // flight is the same at every k-step.
+  f32x4 wf[4][NPL];
+  const unsigned s_w_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint4 *)s_w +
+                            (unsigned)(h * 32 + li) * 16u;
+  auto load_frag = [&](int seq, auto ks_tag) __attribute__((always_inline)) {  // k-step ks of tile seq
+    constexpr int ks = decltype(ks_tag)::value, slot = ks == KS - 1 ? 3 : ks % 3;
+    const unsigned at = s_w_addr + (unsigned)(seq % kRing) * (unsigned)(kTileU4 * 16);
+    static_for<NPL>([&](auto q_tag) __attribute__((always_inline)) {
+      constexpr int q = decltype(q_tag)::value;
+      lds_hidden_read_at<(q * 2 * KS + 2 * ks) * 32 * 16>(wf[slot][q], at);
+    });
+  };
+  // One step: the matrix instructions of W tile seq into acc_new (from zero: the bias is a k
+  // column), with the squares of the previous tile's values (acc_old) between them.  On entry
+  // tiles seq and seq + 1 are in LDS, and the fragments of k-steps 0 .. kAhead-1 of tile seq
+  // have been requested from LDS.
+#ifdef AMLIKE_ROWS_STAMPS
+  unsigned long long st_mfma = 0, st_wait = 0, st_bar = 0, st_steps = 0, st_last = __builtin_readcyclecounter();
+  const unsigned long long st_begin = st_last, st_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // A wave whose 32 rows lie beyond the job's rows (short jobs of the last round) only does its
+  // share of the W stream and keeps the barriers: the SIMD it sits on is then its partner's alone.
+  const bool active = w * 32 < nrows;
+  auto step = [&](int seq, TileAcc &acc_new, const TileAcc &acc_old, auto work_tag) __attribute__((always_inline)) {
+    constexpr bool kWork = decltype(work_tag)::value;
+    if (!active) {
+#if !(AMLIKE_ROWS_ABL & 2)
+      request(seq + kLead);
+#endif
+      wait_vector_memory_but<(kLead - 2) * kMine>();
+      barrier_only();
+      return;
+    }
+    static_for<KS>([&](auto ks_tag) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ks_tag)::value;
+#if !(AMLIKE_ROWS_ABL & 4)  // (timing experiment: the fragments of W are whatever the registers hold)
+      if constexpr (ks + kAhead < KS) load_frag(seq, std::integral_constant<int, (ks + kAhead) % KS>());
+      else load_frag(seq + 1, std::integral_constant<int, (ks + kAhead) % KS>());
+#endif
+      // (past the end of the stream the request wraps around: harmless, and it keeps the count
+      // of outstanding loads the same in every step)
+#if !(AMLIKE_ROWS_ABL & 2)  // (timing experiment: the W stream stops after its first tiles)
+      if constexpr (ks == 0) request(seq + kLead);
+#endif
+      constexpr int slot = ks == KS - 1 ? 3 : ks % 3;
+#if !(AMLIKE_ROWS_ABL & 4)
+      lds_hidden_wait_but<kAhead * NPL>(wf[slot][0], wf[slot][1]);  // all but the reads of the k-steps ahead
+#endif
+      static_for<NPROD>([&](auto j_tag) __attribute__((always_inline)) {
+        // order within a k-step: cross product, high parts, cross product (y, x, y)
+        constexpr int j = decltype(j_tag)::value, mi = ks * NPROD + j;
+        // the fragments of X live in the accumulation registers, the accumulators in the ordinary ones
+        if constexpr (j == 0) mfma_f16_asm_vacc<ks == 0>(acc_new.y, wf[slot][1], xf[ks][0]);
+        else if constexpr (j == 1) mfma_f16_asm_vacc<ks == 0>(acc_new.x, wf[slot][0], xf[ks][0]);
+        else mfma_f16_asm_vacc<false>(acc_new.y, wf[slot][0], xf[ks][1]);
+        // The previous tile's values are read from the fourth matrix instruction of the step on: by
+        // then the last matrix instruction of the previous step has long delivered its result.
+        if constexpr (kWork && !(AMLIKE_ROWS_ABL & 1) && mi >= kSkip) {  // (bit 0, timing experiment: no vector work)
+          constexpr int u0 = ((mi - kSkip) * NE + NMF - kSkip - 1) / (NMF - kSkip),
+                        u1 = ((mi - kSkip + 1) * NE + NMF - kSkip - 1) / (NMF - kSkip);
+          static_for<u1 - u0>([&](auto d) __attribute__((always_inline)) {
+            square_unit(acc_old, std::integral_constant<int, u0 + decltype(d)::value>());
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+#ifdef AMLIKE_ROWS_STAMPS
+    const unsigned long long t1 = __builtin_readcyclecounter();
+#endif
+    // tile seq + 2 has landed; every wave has finished reading tile seq
+    wait_vector_memory_but<(kLead - 2) * kMine>();
+#ifdef AMLIKE_ROWS_STAMPS
+    const unsigned long long t2 = __builtin_readcyclecounter();
+#endif
+    barrier_only();
+#ifdef AMLIKE_ROWS_STAMPS
+    const unsigned long long t3 = __builtin_readcyclecounter();
+    st_mfma += t1 - st_last;
+    st_wait += t2 - t1;
+    st_bar += t3 - t2;
+    st_last = t3;
+    ++st_steps;
+#endif
+  };
+  TileAcc acc_a, acc_b;
+  wait_vector_memory_but<(kLead - 2) * kMine>();
+  barrier_only();  // tiles 0 and 1 are in LDS
+#if AMLIKE_ROWS_ABL & 4
+  static_for<4>([&](auto sl) __attribute__((always_inline)) {
+    wf[decltype(sl)::value][0] = (f32x4){1.0f, 0.5f, 0.25f, 2.0f};
+    wf[decltype(sl)::value][1] = (f32x4){1.0f, 0.5f, 0.25f, 2.0f};
+  });
+#else
+  if (active) static_for<kAhead>([&](auto j) __attribute__((always_inline)) { load_frag(0, j); });
+#endif
+  step(0, acc_a, acc_b, std::false_type());
+  // the squares of tile t - 1 ride in step t; tile t - 1 closes a super-tile when t % 5 == 0
+  for (int t = 1; t < ntile; t += 2) {
+    step(t, acc_b, acc_a, std::true_type());
+    if (t % 5 == 0) finish_groups(t / 5 - 1);
+    if (t + 1 < ntile) {
+      step(t + 1, acc_a, acc_b, std::true_type());
+      if ((t + 1) % 5 == 0) finish_groups((t + 1) / 5 - 1);
+    }
+  }
+  // the last tile's values (ntile odd: set a was written last)
+  if (!active) {
+    wait_vector_memory_but<0>();
+    return;
+  }
+  mfma_result_gap();
+  static_for<NE>([&](auto i) __attribute__((always_inline)) {
+    if (ntile & 1) square_unit(acc_a, i);
+    else square_unit(acc_b, i);
+  });
+  finish_groups(ntile / 5 - 1);
+  wait_vector_memory_but<0>();  // no load may still be on its way into LDS when the block ends
+#ifdef AMLIKE_ROWS_STAMPS
+  if (blockIdx.x == 0 && lane == 0 && (w == 0 || w == 4)) {
+    unsigned long long *o = g_rows_stamps + (w ? 8 : 0);
+    o[0] = st_mfma;
+    o[1] = st_wait;
+    o[2] = st_bar;
+    o[3] = st_steps;
+    o[4] = __builtin_readcyclecounter() - st_begin;
+    o[5] = __builtin_amdgcn_s_memrealtime() - st_real0;
+  }
+#endif
+}
+
 // Softmax for rows wider than the register form holds: three passes over the row.
 __global__ void __launch_bounds__(256)
     nnet_softmax_wide_kernel(const float *__restrict__ in, int ld_in, int dim, int rows, int post,
@@ -1643,6 +1936,7 @@ struct Stage {
   uint4 *d_wpo = nullptr;   // the planes in k-octet-major order: [3][Kp/8][out_dim] x 16 bytes
   // affine followed by a p = 2 p-norm whose group size divides 80: the fused kernel's image
   uint4 *d_wpn = nullptr;   // rows permuted and padded to Npad, bias as column in_dim: [3][Kpn/8][Npad]
+  uint4 *d_wpr = nullptr;   // the same in the row order of nnet_pnorm_rows_kernel (fp16x2, groups of 10, Kpn = 208)
   int fuse_gs = 0, Kpn = 0, Npad = 0;
   // 1: operands as fp16x2 (input behind a NormalizeComponent, weights inside the fp16 range);
   // 2: fp16x2 on trial (weights fit, input range unknown): d_wpo_safe / d_wpn_safe hold the
@@ -1666,6 +1960,7 @@ struct amlike_nnet {
   int num_priors = 0;
   bool gemm_f32 = false;  // AMLIKE_NNET_GEMM=f32: the exact-fp32 MFMA GEMM (A/B check of the bf16x3 one)
   bool gemm_inline_split = false;  // AMLIKE_NNET_GEMM=inline: bf16x3 GEMM that splits X in its k-loop
+  int pnorm_rows = 1;  // AMLIKE_NNET_PNORM_ROWS=0: never the row-stationary affine + p-norm kernel (A/B aid)
   int pnorm_xcd_order = 1;  // AMLIKE_NNET_PNORM_XCD=0: launch-order block mapping in the affine + p-norm kernel (A/B aid)
   float *d_log_priors = nullptr;
   hipStream_t stream = nullptr;
@@ -1703,6 +1998,7 @@ static void FreeNnet(amlike_nnet *n) {
     (void)hipFree(s.d_wp);
     (void)hipFree(s.d_wpo);
     (void)hipFree(s.d_wpn);
+    (void)hipFree(s.d_wpr);
     (void)hipFree(s.d_wpo_safe);
     (void)hipFree(s.d_wpn_safe);
     (void)hipFree(s.d_bias);
@@ -1779,6 +2075,72 @@ static std::vector<uint16_t> BuildPnormWeights(const std::vector<float> &w, int 
   }
   (void)kp8;
   return out;
+}
+
+// The operand image of nnet_pnorm_rows_kernel (groups of 10): unit 10 g + j of group g sits, with
+// blk = g / 16, hh = (g % 16) / 8, in tile 5 blk + j / 2 at the matrix row that accumulator
+// register r = g % 8 + 8 (j % 2) of half-wave hh holds, (r & 3) + 8 (r >> 2) + 4 hh; the bias as
+// column K; rows padded to a multiple of 160, columns to a multiple of 16; fp16x2 planes in
+// k-octet-major order.
+static std::vector<uint16_t> BuildPnormRowsWeights(const std::vector<float> &w, int ldw,
+                                                   const std::vector<float> &bias, int N, int K,
+                                                   int *Kpn, int *Npad) {
+  *Kpn = RoundUp(K + 1, 16);
+  *Npad = RoundUp(N, 160);
+  const size_t np = *Npad;
+  std::vector<uint16_t> out(2 * np * *Kpn, 0);
+  for (int u = 0; u < N; ++u) {
+    const int g = u / 10, j = u % 10;
+    const int blk = g / 16, hh = (g % 16) / 8, r = g % 8 + 8 * (j % 2);
+    const int rho = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    const size_t row = (size_t)blk * 160 + (j / 2) * 32 + rho;
+    for (int k = 0; k <= K; ++k) {
+      uint16_t parts[3];
+      SplitParts(k < K ? w[(size_t)u * ldw + k] : bias[u], 1, parts);
+      for (int q = 0; q < 2; ++q)
+        out[q * np * *Kpn + (((size_t)(k / 8) * np + row) * 8) + (k % 8)] = parts[q];
+    }
+  }
+  return out;
+}
+
+static int LaunchPnormRows(const Stage &s, const uint4 *xp, size_t xplane, float *y, int ldy, int rows, int G,
+                           hipStream_t st) {
+  // Jobs: as many full rounds of 256-row jobs as the CUs take evenly, then the rest in equal
+  // shares (multiples of 32 rows) so that the last round is short everywhere.
+  const int cus = std::max(1, NumComputeUnits());
+  RowJobs jobs;
+  jobs.nbig = (rows / 256 / cus) * cus;
+  const int rest = rows - jobs.nbig * 256;
+  jobs.small = 256;
+  int nsmall = 0;
+  if (rest > 0) {
+    jobs.small = std::min(256, RoundUp((rest + cus - 1) / cus, 32));
+    nsmall = (rest + jobs.small - 1) / jobs.small;
+  }
+  const int grid = jobs.nbig + nsmall;
+  const int KS = s.Kpn / 16;
+  const size_t wplane = (size_t)s.Npad * (s.Kpn / 8);
+  const size_t smem = (size_t)PnormRowsRing(KS) * 2 * 2 * KS * 32 * sizeof(uint4);
+  AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nnet_pnorm_rows_kernel<13>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL((nnet_pnorm_rows_kernel<13>), dim3(grid), dim3(512), smem, st, xp, xplane, s.d_wpr, wplane,
+                     s.Npad, y, ldy, rows, G, jobs);
+  AMLIKE_HIP(hipGetLastError());
+#ifdef AMLIKE_ROWS_STAMPS
+  {
+    AMLIKE_HIP(hipStreamSynchronize(st));
+    unsigned long long hs[16];
+    if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_rows_stamps), sizeof(hs)) == hipSuccess && hs[3])
+      for (int k = 0; k < 2; ++k)
+        fprintf(stderr, "rows kernel job 0 wave %d: per step %.0f ticks = matrix part %.0f + load wait %.0f + barrier %.0f; "
+                "whole job %.0f ticks in %.2f us (%.2f GHz), %llu steps\n", 4 * k,
+                (double)(hs[8 * k] + hs[8 * k + 1] + hs[8 * k + 2]) / hs[8 * k + 3], (double)hs[8 * k] / hs[8 * k + 3],
+                (double)hs[8 * k + 1] / hs[8 * k + 3], (double)hs[8 * k + 2] / hs[8 * k + 3], (double)hs[8 * k + 4],
+                hs[8 * k + 5] * 0.01, hs[8 * k + 4] / (hs[8 * k + 5] * 10.0), hs[8 * k + 3]);
+  }
+#endif
+  return AMLIKE_OK;
 }
 
 // Does the fused output-layer + softmax kernel take stage si (an AffineComponent) and the
@@ -2085,6 +2447,12 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         split(0, pbase + 2 * pstride, 2);
         AMLIKE_HIP(hipGetLastError());
         fused(0, pbase + 2 * pstride, s.d_wpn_safe, 2);
+      } else if (s.d_wpr && cur_rows >= 64) {
+        // rows stationary: X read once per job, the units streamed (nnet_pnorm_rows_kernel)
+        split(s.f16, pbase, 0);
+        AMLIKE_HIP(hipGetLastError());
+        rc = LaunchPnormRows(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, pdst, pld, (int)cur_rows, G, st);
+        if (rc != AMLIKE_OK) return rc;
       } else {
         split(s.f16, pbase, 0);
         AMLIKE_HIP(hipGetLastError());
@@ -2316,6 +2684,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
     n->gemm_inline_split = strcmp(e, "inline") == 0;
   }
   if (const char *e = getenv("AMLIKE_NNET_PNORM_XCD")) n->pnorm_xcd_order = e[0] != '0';
+  if (const char *e = getenv("AMLIKE_NNET_PNORM_ROWS")) n->pnorm_rows = e[0] != '0';
   n->input_dim = comps[0].input_dim;
   int dim = comps[0].input_dim;
   int rc = AMLIKE_OK;
@@ -2428,6 +2797,16 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
               e = hipMalloc(&a.d_wpn_safe, safe.size() * sizeof(uint16_t));
               if (e == hipSuccess)
                 e = hipMemcpy(a.d_wpn_safe, safe.data(), safe.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+            }
+            // the row-stationary kernel's image: fp16x2 operands behind a NormalizeComponent,
+            // groups of 10, k of 13 steps with the bias column (AMLIKE_NNET_PNORM_ROWS=0: A/B aid)
+            if (e == hipSuccess && a.f16 == 1 && gs == 10 && a.Kpn == 208 && n->pnorm_rows) {
+              int kpn2 = 0, npad2 = 0;
+              std::vector<uint16_t> rows_img = BuildPnormRowsWeights(a.h_w, a.Kp, a.h_b, a.out_dim, a.in_dim,
+                                                                     &kpn2, &npad2);
+              e = hipMalloc(&a.d_wpr, rows_img.size() * sizeof(uint16_t));
+              if (e == hipSuccess)
+                e = hipMemcpy(a.d_wpr, rows_img.data(), rows_img.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
             }
             if (e != hipSuccess) {
               SetError("amlike_nnet_create: %s", hipGetErrorString(e));
