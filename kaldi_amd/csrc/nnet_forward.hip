@@ -1108,6 +1108,19 @@ __device__ __forceinline__ void lds_hidden_read_at(f32x4 &v, unsigned addr) {  /
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFFSET));
 #endif
 }
+// The same for a register set that matrix instructions written as assembly read as an operand: `v`
+// counts as in use from its previous contents on ("+v"), so the compiler gives those registers to
+// nothing else between the last matrix instruction that reads them and this read.  (A matrix
+// instruction fetches its operands when the pipe takes it up, tens of cycles after it was issued
+// if others are queued in front; the compiler, which does not know the assembly is a matrix
+// instruction, had put address arithmetic of the next step into the registers of the last
+// fragment: every row's softmax sum came out wrong by a few 1e-3.)
+template <int OFFSET>
+__device__ __forceinline__ void lds_hidden_reload_at(f32x4 &v, unsigned addr) {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(v) : "v"(addr), "n"(OFFSET));
+#endif
+}
 template <int OFFSET>
 __device__ __forceinline__ void lds_hidden_write_at(unsigned addr, const f32x4 &v) {
 #if __HIP_DEVICE_COMPILE__
@@ -1713,6 +1726,10 @@ __global__ void __launch_bounds__(512, 2)
   // ring slot that holds some older tile; the values are not used): the count of reads in
   // flight is the same at every k-step.
   f32x4 wf[4][NPL];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) wf[sl][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   const unsigned s_w_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint4 *)s_w +
                             (unsigned)(h * 32 + li) * 16u;
   auto load_frag = [&](int seq, auto ks_tag) __attribute__((always_inline)) {  // k-step ks of tile seq
@@ -1720,7 +1737,7 @@ __global__ void __launch_bounds__(512, 2)
     const unsigned at = s_w_addr + (unsigned)(seq % kRing) * (unsigned)(kTileU4 * 16);
     static_for<NPL>([&](auto q_tag) __attribute__((always_inline)) {
       constexpr int q = decltype(q_tag)::value;
-      lds_hidden_read_at<(q * 2 * KS + 2 * ks) * 32 * 16>(wf[slot][q], at);
+      lds_hidden_reload_at<(q * 2 * KS + 2 * ks) * 32 * 16>(wf[slot][q], at);
     });
   };
   // One step: the matrix instructions of W tile seq into acc_new (from zero: the bias is a k
@@ -1781,6 +1798,11 @@ __global__ void __launch_bounds__(512, 2)
 #ifdef AMLIKE_ROWS_STAMPS
     const unsigned long long t1 = __builtin_readcyclecounter();
 #endif
+    // Every LDS read of this step has delivered before the step ends: the compiler takes a
+    // register for written as soon as the read that fills it has been issued, and may copy it
+    // when the loop turns round.
+    lds_hidden_wait_but<0>(wf[0][0], wf[0][1]);
+    lds_hidden_wait_but<0>(wf[1][0], wf[1][1]);
     // tile seq + 2 has landed; every wave has finished reading tile seq
     wait_vector_memory_but<(kLead - 2) * kMine>();
 #ifdef AMLIKE_ROWS_STAMPS
