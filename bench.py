@@ -211,6 +211,24 @@ def host_to_host_rate(am, feats, P, chunk_frames=32768):
                    "host buffers; includes the copy of the features up and of the [T x %d] result down" % (chunk, P)}
 
 
+def setup_workload(config, utts_per_gpu, world, rank):
+    """One rank's share of the synthetic workload, host side only (NumPy, no GPU call): the model
+    (the same on every rank), the rank's frames (weak scaling: utts_per_gpu utterances per rank,
+    sharded by utterance, longest first) and their padded feature matrix.  Every rank of a node
+    runs this at the same time before the first barrier; for the swbd tri4 shape at world = 8 it
+    takes about 2 s and 0.4 GB per rank (tests/test_sharding_cpu.py holds it to that)."""
+    D, P, G = synth.GMM_CONFIGS[config]
+    model = synth.make_gmm(D, P, G, seed=777)
+    lengths = synth.utterance_lengths(utts_per_gpu * world, 200, 1500, seed=779)
+    owner = shard_utterances(lengths, world)
+    mine = np.nonzero(owner == rank)[0]
+    T = int(lengths[mine].sum())
+    ldp = (D + 3) // 4 * 4
+    feats = np.zeros((T, ldp), np.float32)
+    feats[:, :D] = synth.make_feats(model, T, seed=1000 + rank)
+    return model, T, ldp, feats
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,19 +282,10 @@ def main():
     _lib.check(_lib.lib().amlike_init(dev.index))
 
     D, P, G = synth.GMM_CONFIGS[args.config]
-    model = synth.make_gmm(D, P, G, seed=777)
+    model, T, ldp, feats = setup_workload(args.config, args.utts_per_gpu, world, rank)
     G = int(model["pdf_offsets"][-1])
     am = gmm.AmDiagGmm(model["weights"], model["means_invvars"], model["inv_vars"],
                        model["pdf_offsets"])
-
-    # Weak scaling: utts-per-gpu utterances per rank, sharded by utterance.
-    lengths = synth.utterance_lengths(args.utts_per_gpu * world, 200, 1500, seed=779)
-    owner = shard_utterances(lengths, world)
-    mine = np.nonzero(owner == rank)[0]
-    T = int(lengths[mine].sum())
-    ldp = (D + 3) // 4 * 4
-    feats = np.zeros((T, ldp), np.float32)
-    feats[:, :D] = synth.make_feats(model, T, seed=1000 + rank)
     d_feats = torch.from_numpy(feats).to(dev)
     d_out = torch.empty((T, P), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -308,6 +317,13 @@ def main():
     # Summary statistics, all-reduced like the reference binaries' totals.
     (tot_like, tot_frames), elapsed = reduce_summary(
         dist, [d_out.max(dim=1).values.double().sum().item(), float(T)], elapsed, device=dev if backend == "nccl" else None)
+    # The job's collective work ends here: the process group is taken down before rank 0 goes on
+    # to its single-GPU extras (host-to-host rate, nnet2 leg, CPU baseline: tens of seconds), so
+    # that no rank sits in a barrier meanwhile and no RCCL watchdog is in play.
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
 
     # Dominant kernel: mean of the event-bracketed durations collected over the timed region.
     if timed_launches == 0:  # more than 256 steps: fall back to a separate timing loop
@@ -391,9 +407,6 @@ def main():
             except ImportError:
                 pass
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -87,3 +87,33 @@ def test_two_rank_gloo_job_matches_single_process():
         assert tot_frames == float(lengths.sum()) and n_utts == 24.0
         assert abs(tot_like - want_like) < 1e-9 * max(1.0, abs(want_like)) + 1e-9
         assert t == 0.5  # max over ranks
+
+
+def test_bench_setup_for_eight_ranks_is_light():
+    """bench.py's host-side set-up as every rank of an 8-GPU run performs it, all at once, before the
+    first barrier (the 200 000-Gaussian model and the rank's ~217 k frames, NumPy only): measured
+    2 s and 0.4 GB per rank; held here to 30 s and 1.5 GB, in a process of its own so that the peak
+    memory is this work's."""
+    import subprocess
+    import sys
+    code = (
+        "import json, resource, sys, time\n"
+        "sys.argv = ['bench.py']\n"
+        "import bench\n"
+        "out = {}\n"
+        "for rank in (0, 7):\n"
+        "    t0 = time.time()\n"
+        "    model, T, ldp, feats = bench.setup_workload('swbd_tri4', 256, 8, rank)\n"
+        "    out[rank] = dict(secs=time.time() - t0, T=T, shape=list(feats.shape), G=int(model['pdf_offsets'][-1]))\n"
+        "out['rss_mb'] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0\n"
+        "print(json.dumps(out))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    import json
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    for rank in ("0", "7"):
+        assert out[rank]["secs"] < 30.0
+        assert out[rank]["G"] == 200000 and out[rank]["shape"] == [out[rank]["T"], 40]
+        assert 200000 < out[rank]["T"] < 235000  # 256 utterances of ~U[200, 1500] frames
+    assert out["rss_mb"] < 1536.0
