@@ -234,34 +234,46 @@ int amlike_gmm_score_raw(amlike_gmm_t *gmm, amlike_xform_t *xf, const float *raw
 
 /* ---- nnet2 forward -------------------------------------------------------- */
 
-/* Component kinds of the p-norm nnet2 forward path
+/* Component kinds of the nnet2 forward path
  * (nnet2/nnet-component.cc: Splice :2411-2471, FixedAffine :3028-3034,
  * Affine / AffineComponentPreconditioned(Online) :1123-1131, Pnorm :530-535,
- * Normalize :578-592, Softmax :905-918, SumGroup :2352-2357, and the
- * elementwise Sigmoid :639, Tanh :673, RectifiedLinear :782). */
+ * Normalize :578-592, Softmax :905-918, SumGroup :2352-2357, the elementwise
+ * Sigmoid :639, Tanh :673, RectifiedLinear :782, SoftHinge :810-816, Power :731-737,
+ * Scale :844-850, FixedScale :3103-3109, FixedBias :3171-3177, and Maxout :443-454,
+ * Permute :2262-2270, Dct :2802-2830, FixedLinear :2948-2953). */
 enum amlike_component_kind {
   AMLIKE_SPLICE = 1,
-  AMLIKE_AFFINE = 2, /* also FixedAffine: out = in * W^T + b, W is [out_dim x in_dim] */
+  AMLIKE_AFFINE = 2, /* also FixedAffine, and FixedLinear / a BlockAffine written out densely with
+                        bias == NULL or the full bias: out = in * W^T + b, W is [out_dim x in_dim] */
   AMLIKE_PNORM = 3,
   AMLIKE_NORMALIZE = 4,
   AMLIKE_SOFTMAX = 5,
   AMLIKE_SUMGROUP = 6,
   AMLIKE_SIGMOID = 7,
   AMLIKE_TANH = 8,
-  AMLIKE_RELU = 9
+  AMLIKE_RELU = 9,
+  AMLIKE_SOFTHINGE = 10,   /* x > 10 ? x : log1p(exp(x))  (matrix/kaldi-matrix.cc:2434-2448) */
+  AMLIKE_POWER = 11,       /* |x|^p  (matrix/kaldi-vector.cc:496-525, include_sign = false) */
+  AMLIKE_SCALE = 12,       /* p * x */
+  AMLIKE_FIXED_SCALE = 13, /* x[c] * bias[c]: `bias` holds the <Scales> vector */
+  AMLIKE_FIXED_BIAS = 14,  /* x[c] + bias[c] */
+  AMLIKE_MAXOUT = 15,      /* max over consecutive groups of input_dim / output_dim columns, not below -1e20 */
+  AMLIKE_PERMUTE = 16,     /* out[sizes[i]] = in[i]: `sizes` holds <Reorder>, a permutation of 0..dim-1 */
+  AMLIKE_DCT = 17          /* per block of const_dim columns a DCT keeping the first output_dim /
+                              (input_dim / const_dim) coefficients; left_context != 0: <Reorder> true */
 };
 
 typedef struct amlike_component {
   int32_t kind;          /* enum amlike_component_kind */
   int32_t input_dim;
   int32_t output_dim;
-  int32_t left_context;  /* SPLICE */
+  int32_t left_context;  /* SPLICE; DCT: the reorder flag */
   int32_t right_context; /* SPLICE */
-  int32_t const_dim;     /* SPLICE: const_component_dim_ */
-  float p;               /* PNORM */
+  int32_t const_dim;     /* SPLICE: const_component_dim_; DCT: dct_dim */
+  float p;               /* PNORM, POWER: the exponent; SCALE: the factor */
   const float *linear;   /* AFFINE: [output_dim x input_dim] row-major, dense */
-  const float *bias;     /* AFFINE: [output_dim] */
-  const int32_t *sizes;  /* SUMGROUP: [output_dim] group sizes */
+  const float *bias;     /* AFFINE: [output_dim] or NULL (no offset); FIXED_SCALE, FIXED_BIAS: [input_dim] */
+  const int32_t *sizes;  /* SUMGROUP: [output_dim] group sizes; PERMUTE: [input_dim] */
 } amlike_component_t;
 
 /* Replaces Nnet (nnet2/nnet-nnet.h:62-) + AmNnet::Priors (nnet2/am-nnet.h) as a

@@ -157,12 +157,110 @@ static Component ReadComponent(std::istream &is, bool binary) {
       if (s <= 0) KaldiErr("SumGroupComponent: sizes must be positive");
       c.input_dim += s;
     }
+  } else if (c.type == "BlockAffineComponent" || c.type == "BlockAffineComponentPreconditioned") {
+    // :2045-2055, :2135-2150; Propagate :1907-1939: block b of the output = block b of the
+    // input times its [output block x input block] slice of the stacked parameter matrix.
+    // Written out as the dense block-diagonal matrix it stands for.
+    c.kind = AMLIKE_AFFINE;
+    ExpectOneOrTwoTokens(is, binary, token, "<LearningRate>");
+    float f;
+    ReadBasicType(is, binary, &f);
+    ExpectToken(is, binary, "<NumBlocks>");
+    int32 num_blocks;
+    ReadBasicType(is, binary, &num_blocks);
+    Matrix stacked;
+    ExpectToken(is, binary, "<LinearParams>");
+    stacked.Read(is, binary);
+    ExpectToken(is, binary, "<BiasParams>");
+    c.bias.Read(is, binary);
+    if (c.type == "BlockAffineComponentPreconditioned") {
+      ExpectToken(is, binary, "<Alpha>");
+      ReadBasicType(is, binary, &f);
+      ExpectToken(is, binary, "<IsGradient>");
+      bool g;
+      ReadBasicType(is, binary, &g);
+    }
+    ExpectToken(is, binary, end.c_str());
+    if (num_blocks <= 0 || stacked.NumRows() % num_blocks != 0 || c.bias.Dim() != stacked.NumRows())
+      KaldiErr("BlockAffineComponent: parameters do not match the number of blocks");
+    const int32 in_block = stacked.NumCols(), out_block = stacked.NumRows() / num_blocks;
+    c.input_dim = in_block * num_blocks;
+    c.output_dim = stacked.NumRows();
+    c.linear.Resize(c.output_dim, c.input_dim);
+    for (int32 r = 0; r < c.output_dim; ++r)
+      std::copy(stacked.RowData(r), stacked.RowData(r) + in_block,
+                c.linear.RowData(r) + static_cast<size_t>(r / out_block) * in_block);
+  } else if (c.type == "FixedLinearComponent") {  // :2979-2983
+    c.kind = AMLIKE_AFFINE;
+    ExpectOneOrTwoTokens(is, binary, token, "<CuMatrix>");
+    c.linear.Read(is, binary);
+    ExpectToken(is, binary, end.c_str());
+    c.output_dim = c.linear.NumRows();
+    c.input_dim = c.linear.NumCols();
+  } else if (c.type == "FixedScaleComponent" || c.type == "FixedBiasComponent") {  // :3134-3138, :3201-3205
+    const bool scale = c.type == "FixedScaleComponent";
+    c.kind = scale ? AMLIKE_FIXED_SCALE : AMLIKE_FIXED_BIAS;
+    ExpectOneOrTwoTokens(is, binary, token, scale ? "<Scales>" : "<Bias>");
+    c.bias.Read(is, binary);
+    ExpectToken(is, binary, end.c_str());
+    c.input_dim = c.output_dim = c.bias.Dim();
+  } else if (c.type == "ScaleComponent") {  // :891-897
+    c.kind = AMLIKE_SCALE;
+    ExpectOneOrTwoTokens(is, binary, token, "<Dim>");
+    ReadBasicType(is, binary, &c.input_dim);
+    ExpectToken(is, binary, "<Scale>");
+    ReadBasicType(is, binary, &c.p);
+    ExpectToken(is, binary, end.c_str());
+    c.output_dim = c.input_dim;
+  } else if (c.type == "PowerComponent") {  // :754-762
+    c.kind = AMLIKE_POWER;
+    ExpectOneOrTwoTokens(is, binary, token, "<InputDim>");
+    ReadBasicType(is, binary, &c.input_dim);
+    ExpectToken(is, binary, "<OutputDim>");
+    ReadBasicType(is, binary, &c.output_dim);
+    ExpectToken(is, binary, "<Power>");
+    ReadBasicType(is, binary, &c.p);
+    ExpectToken(is, binary, end.c_str());
+  } else if (c.type == "MaxoutComponent") {  // :481-487
+    c.kind = AMLIKE_MAXOUT;
+    ExpectOneOrTwoTokens(is, binary, token, "<InputDim>");
+    ReadBasicType(is, binary, &c.input_dim);
+    ExpectToken(is, binary, "<OutputDim>");
+    ReadBasicType(is, binary, &c.output_dim);
+    ExpectToken(is, binary, end.c_str());
+  } else if (c.type == "PermuteComponent") {  // :2232-2236
+    c.kind = AMLIKE_PERMUTE;
+    ExpectOneOrTwoTokens(is, binary, token, "<Reorder>");
+    ReadIntegerVector(is, binary, &c.sizes);
+    ExpectToken(is, binary, end.c_str());
+    c.input_dim = c.output_dim = static_cast<int32>(c.sizes.size());
+  } else if (c.type == "DctComponent") {  // :2892-2918
+    c.kind = AMLIKE_DCT;
+    ExpectOneOrTwoTokens(is, binary, token, "<Dim>");
+    ReadBasicType(is, binary, &c.input_dim);
+    ExpectToken(is, binary, "<DctDim>");
+    ReadBasicType(is, binary, &c.const_dim);
+    ExpectToken(is, binary, "<Reorder>");
+    ReadBasicType(is, binary, &c.dct_reorder);
+    int32 keep = c.const_dim;
+    ReadToken(is, binary, &tok);
+    if (tok == "<DctKeepDim>") {
+      ReadBasicType(is, binary, &keep);
+      ExpectToken(is, binary, end.c_str());
+    } else if (tok != end) {
+      KALDI_AMD_ERR("Expected token \"" << end << "\", got instead \"" << tok << "\".");
+    }
+    if (keep <= 0) keep = c.const_dim;  // DctComponent::Init :2745
+    if (c.const_dim <= 0 || c.input_dim <= 0 || c.input_dim % c.const_dim != 0 || keep > c.const_dim)
+      KaldiErr("DctComponent: the DCT dimension must divide the dimension and cover the kept part");
+    c.output_dim = keep * (c.input_dim / c.const_dim);
   } else {
     if (c.type == "NormalizeComponent") c.kind = AMLIKE_NORMALIZE;
     else if (c.type == "SoftmaxComponent") c.kind = AMLIKE_SOFTMAX;
     else if (c.type == "SigmoidComponent") c.kind = AMLIKE_SIGMOID;
     else if (c.type == "TanhComponent") c.kind = AMLIKE_TANH;
     else if (c.type == "RectifiedLinearComponent") c.kind = AMLIKE_RELU;
+    else if (c.type == "SoftHingeComponent") c.kind = AMLIKE_SOFTHINGE;
     else KALDI_AMD_ERR("Unknown component type " << c.type);
     ReadNonlinear(is, binary, &c);
   }
@@ -231,9 +329,13 @@ amlike_nnet_t *AmNnet::CreateEngine() const {
           std::copy(c.linear.RowData(r), c.linear.RowData(r) + c.input_dim,
                     dense[i].begin() + static_cast<size_t>(r) * c.input_dim);
         a.linear = dense[i].data();
-        a.bias = c.bias.Data();
-      } else if (c.kind == AMLIKE_SUMGROUP) {
+        a.bias = c.bias.Dim() ? c.bias.Data() : nullptr;  // FixedLinearComponent has none
+      } else if (c.kind == AMLIKE_SUMGROUP || c.kind == AMLIKE_PERMUTE) {
         a.sizes = c.sizes.data();
+      } else if (c.kind == AMLIKE_FIXED_SCALE || c.kind == AMLIKE_FIXED_BIAS) {
+        a.bias = c.bias.Data();
+      } else if (c.kind == AMLIKE_DCT) {
+        a.left_context = c.dct_reorder ? 1 : 0;
       }
     }
     amlike_nnet_t *h = nullptr;

@@ -25,8 +25,10 @@ struct Component {
   std::string type;  // e.g. "AffineComponentPreconditionedOnline"
   int32 kind = 0;    // enum amlike_component_kind
   int32 input_dim = 0, output_dim = 0;
-  int32 left_context = 0, right_context = 0, const_dim = 0;
-  float p = 2.0f;
+  int32 left_context = 0, right_context = 0;
+  int32 const_dim = 0;       // Splice: const_component_dim_; Dct: the DCT dimension
+  bool dct_reorder = false;  // Dct: <Reorder>
+  float p = 2.0f;            // Pnorm, Power: the exponent; Scale: the factor
   Matrix linear;  // [output_dim x input_dim]
   Vector bias;
   std::vector<int32> sizes;

@@ -1917,11 +1917,15 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// Sigmoid / Tanh / RectifiedLinear (matrix/kaldi-vector.cc:937-951, :899-913;
-// nnet-component.cc:782-788), or a pure post-processing pass (kind = 0).
+// The elementwise components: Sigmoid / Tanh / RectifiedLinear (matrix/kaldi-vector.cc:937-951,
+// :899-913; nnet-component.cc:782-788), SoftHinge (matrix/kaldi-matrix.cc:2434-2448), Power
+// (matrix/kaldi-vector.cc:496-525 with include_sign = false), Scale (nnet-component.cc:844-850),
+// FixedScale (:3103-3109) and FixedBias (:3171-3177) with their vector in `vec`, or a pure
+// post-processing pass (kind = 0).
 __global__ void __launch_bounds__(256)
     nnet_elementwise_kernel(const float *__restrict__ in, int ld_in, int dim, int rows, int kind,
-                            int post, const float *__restrict__ log_priors, float scale,
+                            const float *__restrict__ vec, float p, int post,
+                            const float *__restrict__ log_priors, float scale,
                             float *__restrict__ out, int ld_out, int zero_pad) {
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const float *x = in + (size_t)r * ld_in;
@@ -1937,10 +1941,52 @@ __global__ void __launch_bounds__(256)
           v = v > 0.0f ? th : -th;
         } else if (kind == AMLIKE_RELU) {
           v = fmaxf(v, 0.0f);
+        } else if (kind == AMLIKE_SOFTHINGE) {
+          v = v > 10.0f ? v : log1pf(expf(v));
+        } else if (kind == AMLIKE_POWER) {
+          const float a = fabsf(v);
+          if (p == 2.0f) v = v * v;
+          else if (p == 0.5f) v = sqrtf(a);
+          else if (p == 1.0f) v = a;
+          else if (p < 0.0f) v = v == 0.0f ? 0.0f : powf(a, p);
+          else v = powf(a, p);
+        } else if (kind == AMLIKE_SCALE) {
+          v *= p;
+        } else if (kind == AMLIKE_FIXED_SCALE) {
+          v *= vec[c];
+        } else if (kind == AMLIKE_FIXED_BIAS) {
+          v += vec[c];
         }
         o[c] = post_process(v, post, log_priors, c, scale);
       } else if (zero_pad) {
         o[c] = 0.0f;
+      }
+    }
+  }
+}
+
+// Maxout (group > 0: out[j] = the largest of -1e20 and in[j * group .. (j + 1) * group),
+// nnet-component.cc:443-454) and Permute (group == 0: out[c] = in[src[c]], :2262-2270).
+__global__ void __launch_bounds__(256)
+    nnet_regroup_kernel(const float *__restrict__ in, int ld_in, const int32_t *__restrict__ src,
+                        int group, int out_dim, int rows, int post,
+                        const float *__restrict__ log_priors, float scale, float *__restrict__ out,
+                        int ld_out, int zero_pad) {
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float *x = in + (size_t)r * ld_in;
+    float *o = out + (size_t)r * ld_out;
+    for (int j = threadIdx.x; j < ld_out; j += 256) {
+      if (j < out_dim) {
+        float v;
+        if (group > 0) {
+          v = -1.0e20f;
+          for (int c = j * group; c < (j + 1) * group; ++c) v = fmaxf(v, x[c]);
+        } else {
+          v = x[src[j]];
+        }
+        o[j] = post_process(v, post, log_priors, j, scale);
+      } else if (zero_pad) {
+        o[j] = 0.0f;
       }
     }
   }
@@ -2235,6 +2281,46 @@ static int LaunchOutSoftmax(const Stage &s, const uint4 *xp, size_t xplane, cons
   return AMLIKE_OK;
 }
 
+// The dense [out_dim x dim] matrix a DctComponent amounts to (nnet2/nnet-component.cc:2744-2830):
+// the DCT matrix of matrix/matrix-functions.cc:592-608 (its first `keep` rows) applied to each
+// block of dct_dim columns, between the two column reorderings of DctComponent::Reorder when
+// `reorder` is set.  The first of those writes only keep * (dim / dct_dim) positions of a zeroed
+// row, so with keep < dct_dim some inputs are dropped and blocks see zeros: restated as it is.
+static bool BuildDctMatrix(int dim, int dct_dim, int out_dim, bool reorder, std::vector<float> *w) {
+  if (dim <= 0 || dct_dim <= 0 || dim % dct_dim != 0) return false;
+  const int chunks = dim / dct_dim;
+  if (out_dim <= 0 || out_dim % chunks != 0) return false;
+  const int keep = out_dim / chunks;
+  if (keep > dct_dim) return false;
+  std::vector<float> dct((size_t)keep * dct_dim);
+  {
+    float normalizer = (float)std::sqrt(1.0 / (double)(float)dct_dim);
+    for (int n = 0; n < dct_dim; ++n) dct[n] = normalizer;
+    normalizer = (float)std::sqrt(2.0 / (double)(float)dct_dim);
+    for (int k = 1; k < keep; ++k)
+      for (int n = 0; n < dct_dim; ++n)
+        dct[(size_t)k * dct_dim + n] = (float)((double)normalizer * std::cos(M_PI / dct_dim * (n + 0.5) * k));
+  }
+  // src_of[q]: the input column that position q of the (reordered) row holds, or -1 for a zero
+  std::vector<int> src_of(dim), dst_of(out_dim);
+  for (int q = 0; q < dim; ++q) src_of[q] = reorder ? -1 : q;
+  for (int m = 0; m < out_dim; ++m) dst_of[m] = m;
+  if (reorder) {
+    for (int b = 0; b < keep; ++b)
+      for (int j = 0; j < chunks; ++j) src_of[j * keep + b] = b * chunks + j;
+    for (int b = 0; b < chunks; ++b)
+      for (int j = 0; j < keep; ++j) dst_of[b * keep + j] = j * chunks + b;
+  }
+  w->assign((size_t)out_dim * dim, 0.0f);
+  for (int ch = 0; ch < chunks; ++ch)
+    for (int k = 0; k < keep; ++k)
+      for (int n = 0; n < dct_dim; ++n) {
+        const int src = src_of[ch * dct_dim + n];
+        if (src >= 0) (*w)[(size_t)dst_of[ch * keep + k] * dim + src] = dct[(size_t)k * dct_dim + n];
+      }
+  return true;
+}
+
 static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *utt_rows,
                    int num_utts, int pad_input, int mode, float prob_scale, float *d_out, int ldo,
                    hipStream_t st, int64_t *total_out_rows) {
@@ -2524,7 +2610,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       if (pn_last && post) {
         const int blocks = (int)std::min<int64_t>(cur_rows, 16384);
         hipLaunchKernelGGL(nnet_elementwise_kernel, dim3(blocks), dim3(256), 0, st, d_out, ldo, G,
-                           (int)cur_rows, 0, post, n->d_log_priors, prob_scale, d_out, ldo, 0);
+                           (int)cur_rows, 0, nullptr, 0.0f, post, n->d_log_priors, prob_scale, d_out, ldo, 0);
         AMLIKE_HIP(hipGetLastError());
       }
       cur = fin;
@@ -2659,11 +2745,17 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
                          s.out_dim, (int)cur_rows, spost, n->d_log_priors, prob_scale, dst, dst_ld,
                          zero_pad);
       AMLIKE_HIP(hipGetLastError());
+    } else if (s.kind == AMLIKE_MAXOUT || s.kind == AMLIKE_PERMUTE) {
+      const int blocks = (int)std::min<int64_t>(cur_rows, 16384);
+      hipLaunchKernelGGL(nnet_regroup_kernel, dim3(blocks), dim3(256), 0, st, cur, cur_ld, s.d_begins,
+                         s.kind == AMLIKE_MAXOUT ? s.in_dim / s.out_dim : 0, s.out_dim, (int)cur_rows,
+                         spost, n->d_log_priors, prob_scale, dst, dst_ld, zero_pad);
+      AMLIKE_HIP(hipGetLastError());
     } else {
       const int blocks = (int)std::min<int64_t>(cur_rows, 16384);
       hipLaunchKernelGGL(nnet_elementwise_kernel, dim3(blocks), dim3(256), 0, st, cur, cur_ld,
-                         s.in_dim, (int)cur_rows, s.kind, spost, n->d_log_priors, prob_scale, dst,
-                         dst_ld, zero_pad);
+                         s.in_dim, (int)cur_rows, s.kind, s.d_bias, s.p, spost, n->d_log_priors,
+                         prob_scale, dst, dst_ld, zero_pad);
       AMLIKE_HIP(hipGetLastError());
     }
     const bool fused_post = (s.kind == AMLIKE_SOFTMAX || s.kind == AMLIKE_SUMGROUP ||
@@ -2672,7 +2764,8 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       // The last stage has no fused post-processing (e.g. an affine output): one more pass.
       const int blocks = (int)std::min<int64_t>(out_rows, 16384);
       hipLaunchKernelGGL(nnet_elementwise_kernel, dim3(blocks), dim3(256), 0, st, d_out, ldo,
-                         s.out_dim, (int)out_rows, 0, post, n->d_log_priors, prob_scale, d_out, ldo, 0);
+                         s.out_dim, (int)out_rows, 0, nullptr, 0.0f, post, n->d_log_priors, prob_scale,
+                         d_out, ldo, 0);
       AMLIKE_HIP(hipGetLastError());
     }
     cur = dst;
@@ -2722,7 +2815,26 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
     s.kind = c.kind;
     s.in_dim = c.input_dim;
     s.out_dim = c.output_dim;
-    switch (c.kind) {
+    // What the affine stage is built from: the caller's matrix, or the one a DctComponent
+    // amounts to; no bias stands for zeros (FixedLinearComponent).
+    const float *lin = c.linear, *lin_bias = c.bias;
+    std::vector<float> own_lin, zero_bias;
+    if (c.kind == AMLIKE_DCT) {
+      if (!BuildDctMatrix(c.input_dim, c.const_dim, c.output_dim, c.left_context != 0, &own_lin)) {
+        SetError("amlike_nnet_create: bad DctComponent %d (dim %d, dct dim %d, output dim %d)", i,
+                 c.input_dim, c.const_dim, c.output_dim);
+        rc = AMLIKE_EINVAL;
+        break;
+      }
+      lin = own_lin.data();
+      lin_bias = nullptr;
+      s.kind = AMLIKE_AFFINE;
+    }
+    if (s.kind == AMLIKE_AFFINE && lin && !lin_bias && c.output_dim > 0) {
+      zero_bias.assign(c.output_dim, 0.0f);
+      lin_bias = zero_bias.data();
+    }
+    switch (s.kind) {
       case AMLIKE_SPLICE: {
         s.left = c.left_context;
         s.right = c.right_context;
@@ -2738,7 +2850,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
         break;
       }
       case AMLIKE_AFFINE: {
-        if (!c.linear || !c.bias) {
+        if (!lin || !lin_bias || c.input_dim <= 0 || c.output_dim <= 0) {
           SetError("amlike_nnet_create: affine component %d without parameters", i);
           rc = AMLIKE_EINVAL;
           break;
@@ -2746,9 +2858,9 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
         s.Kp = RoundUp(c.input_dim, 16);
         std::vector<float> w((size_t)c.output_dim * s.Kp, 0.0f);
         for (int r = 0; r < c.output_dim; ++r)
-          memcpy(&w[(size_t)r * s.Kp], c.linear + (size_t)r * c.input_dim, c.input_dim * sizeof(float));
+          memcpy(&w[(size_t)r * s.Kp], lin + (size_t)r * c.input_dim, c.input_dim * sizeof(float));
         s.h_w = w;
-        s.h_b.assign(c.bias, c.bias + c.output_dim);
+        s.h_b.assign(lin_bias, lin_bias + c.output_dim);
         std::vector<uint16_t> wp(3 * w.size());
         for (size_t idx = 0; idx < w.size(); ++idx) {
           uint16_t parts[3];
@@ -2760,7 +2872,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
         {
           float wmax = 0.0f;
           for (float v : w) wmax = std::max(wmax, std::fabs(v));
-          for (int r = 0; r < c.output_dim; ++r) wmax = std::max(wmax, std::fabs(c.bias[r]));
+          for (int r = 0; r < c.output_dim; ++r) wmax = std::max(wmax, std::fabs(lin_bias[r]));
           const bool w_ok = std::isfinite(wmax) && wmax <= 1024.0f && !getenv("AMLIKE_NNET_NOF16");
           const bool normalised_input = i > 0 && comps[i - 1].kind == AMLIKE_NORMALIZE;
           s.f16 = !w_ok ? 0 : normalised_input ? 1 : (getenv("AMLIKE_NNET_NOF16TRY") ? 0 : 2);
@@ -2784,7 +2896,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
           // padded to whole 32-unit tiles with -inf: a padding unit then has score -inf in the
           // fused output-layer kernel (no share in the softmax sum); the other kernels stop at out_dim
           std::vector<float> bpad(RoundUp(c.output_dim, 32), -INFINITY);
-          std::copy(c.bias, c.bias + c.output_dim, bpad.begin());
+          std::copy(lin_bias, lin_bias + c.output_dim, bpad.begin());
           if (e == hipSuccess) e = hipMalloc(&s.d_bias, bpad.size() * sizeof(float));
           if (e == hipSuccess)
             e = hipMemcpy(s.d_bias, bpad.data(), bpad.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -2861,11 +2973,60 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
         }
         break;
       }
+      case AMLIKE_FIXED_SCALE:
+      case AMLIKE_FIXED_BIAS: {
+        if (!c.bias || c.input_dim != c.output_dim || c.input_dim <= 0) {
+          SetError("amlike_nnet_create: component %d needs a vector of its dimension", i);
+          rc = AMLIKE_EINVAL;
+          break;
+        }
+        hipError_t e = hipMalloc(&s.d_bias, c.input_dim * sizeof(float));
+        if (e == hipSuccess)
+          e = hipMemcpy(s.d_bias, c.bias, c.input_dim * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+          SetError("amlike_nnet_create: %s", hipGetErrorString(e));
+          rc = AMLIKE_EHIP;
+        }
+        break;
+      }
+      case AMLIKE_MAXOUT:
+        if (c.output_dim <= 0 || c.input_dim <= 0 || c.input_dim % c.output_dim != 0) {
+          SetError("amlike_nnet_create: bad MaxoutComponent %d", i);
+          rc = AMLIKE_EINVAL;
+        }
+        break;
+      case AMLIKE_PERMUTE: {
+        // out(r, c) = in(r, reverse_reorder[c]) with reverse_reorder[reorder[i]] = i
+        std::vector<int32_t> src(std::max(c.input_dim, 0), -1);
+        bool ok = c.sizes && c.input_dim == c.output_dim && c.input_dim > 0;
+        for (int k = 0; ok && k < c.input_dim; ++k) {
+          ok = c.sizes[k] >= 0 && c.sizes[k] < c.input_dim && src[c.sizes[k]] < 0;
+          if (ok) src[c.sizes[k]] = k;
+        }
+        if (!ok) {
+          SetError("amlike_nnet_create: PermuteComponent %d needs a permutation of 0..dim-1", i);
+          rc = AMLIKE_EINVAL;
+          break;
+        }
+        hipError_t e = hipMalloc(&s.d_begins, src.size() * sizeof(int32_t));
+        if (e == hipSuccess)
+          e = hipMemcpy(s.d_begins, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+          SetError("amlike_nnet_create: %s", hipGetErrorString(e));
+          rc = AMLIKE_EHIP;
+        }
+        break;
+      }
+      case AMLIKE_POWER:
+      case AMLIKE_SCALE:
+        s.p = c.p;
+        [[fallthrough]];
       case AMLIKE_NORMALIZE:
       case AMLIKE_SOFTMAX:
       case AMLIKE_SIGMOID:
       case AMLIKE_TANH:
       case AMLIKE_RELU:
+      case AMLIKE_SOFTHINGE:
         if (c.input_dim != c.output_dim) {
           SetError("amlike_nnet_create: component %d must keep the dimension", i);
           rc = AMLIKE_EINVAL;

@@ -17,13 +17,32 @@ POSTERIORS, LOG, LOGLIKES = 0, 1, 2
 
 KINDS = {"SpliceComponent": 1, "FixedAffineComponent": 2, "AffineComponent": 2,
          "AffineComponentPreconditioned": 2, "AffineComponentPreconditionedOnline": 2,
+         "FixedLinearComponent": 2, "BlockAffineComponent": 2, "BlockAffineComponentPreconditioned": 2,
          "PnormComponent": 3, "NormalizeComponent": 4, "SoftmaxComponent": 5,
          "SumGroupComponent": 6, "SigmoidComponent": 7, "TanhComponent": 8,
-         "RectifiedLinearComponent": 9}
+         "RectifiedLinearComponent": 9, "SoftHingeComponent": 10, "PowerComponent": 11,
+         "ScaleComponent": 12, "FixedScaleComponent": 13, "FixedBiasComponent": 14,
+         "MaxoutComponent": 15, "PermuteComponent": 16, "DctComponent": 17}
 
 
 def _fp(a):
     return a.ctypes.data_as(POINTER(c_float))
+
+
+def block_diagonal(stacked, num_blocks):
+    """The dense matrix a BlockAffineComponent stands for (nnet2/nnet-component.cc:1907-1939):
+    block b of the output reads block b of the input through rows [b * out_block, (b + 1) *
+    out_block) of the stacked [num_blocks * out_block x in_block] parameter matrix."""
+    stacked = np.asarray(stacked, np.float32)
+    rows, in_block = stacked.shape
+    if num_blocks <= 0 or rows % num_blocks:
+        raise ValueError("BlockAffineComponent: %d rows do not split into %d blocks" % (rows, num_blocks))
+    out_block = rows // num_blocks
+    W = np.zeros((rows, in_block * num_blocks), np.float32)
+    for b in range(num_blocks):
+        W[b * out_block:(b + 1) * out_block, b * in_block:(b + 1) * in_block] = \
+            stacked[b * out_block:(b + 1) * out_block]
+    return W
 
 
 def _components_to_c(components):
@@ -39,20 +58,45 @@ def _components_to_c(components):
             a.const_dim = c.get("const_dim", 0)
             a.output_dim = (a.input_dim - a.const_dim) * (a.left_context + 1 + a.right_context) + a.const_dim
         elif a.kind == 2:
-            W = np.ascontiguousarray(c["linear"], np.float32)
-            b = np.ascontiguousarray(c["bias"], np.float32)
-            keep += [W, b]
+            W = c["linear"] if "num_blocks" not in c else block_diagonal(c["linear"], c["num_blocks"])
+            W = np.ascontiguousarray(W, np.float32)
+            keep.append(W)
             a.output_dim, a.input_dim = W.shape
-            a.linear, a.bias = _fp(W), _fp(b)
-        elif t == "PnormComponent":
+            a.linear = _fp(W)
+            if c.get("bias") is not None:  # FixedLinearComponent has none
+                b = np.ascontiguousarray(c["bias"], np.float32)
+                if b.shape != (W.shape[0],):
+                    raise ValueError("%s: bias of %s for %d outputs" % (t, b.shape, W.shape[0]))
+                keep.append(b)
+                a.bias = _fp(b)
+        elif t in ("PnormComponent", "MaxoutComponent"):
             a.input_dim, a.output_dim, a.p = c["input_dim"], c["output_dim"], c.get("p", 2.0)
         elif t == "SumGroupComponent":
             s = np.ascontiguousarray(c["sizes"], np.int32)
             keep.append(s)
             a.sizes = s.ctypes.data_as(POINTER(c_int32))
             a.input_dim, a.output_dim = int(s.sum()), len(s)
+        elif t == "PermuteComponent":
+            s = np.ascontiguousarray(c["reorder"], np.int32)
+            keep.append(s)
+            a.sizes = s.ctypes.data_as(POINTER(c_int32))
+            a.input_dim = a.output_dim = len(s)
+        elif t in ("FixedScaleComponent", "FixedBiasComponent"):
+            v = np.ascontiguousarray(c["scales" if t == "FixedScaleComponent" else "bias"], np.float32)
+            keep.append(v)
+            a.bias = _fp(v)
+            a.input_dim = a.output_dim = len(v)
+        elif t == "DctComponent":
+            dct_keep = c.get("dct_keep_dim", 0) or c["dct_dim"]
+            a.input_dim, a.const_dim = c["dim"], c["dct_dim"]
+            a.left_context = 1 if c.get("reorder", False) else 0
+            a.output_dim = dct_keep * (c["dim"] // c["dct_dim"])
         else:
             a.input_dim = a.output_dim = c["dim"]
+            if t == "PowerComponent":
+                a.p = c["power"]
+            elif t == "ScaleComponent":
+                a.p = c["scale"]
     return arr, keep
 
 

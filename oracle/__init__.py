@@ -165,9 +165,13 @@ def _declare_nnet(L):
 
 KINDS = {"SpliceComponent": 1, "FixedAffineComponent": 2, "AffineComponent": 2,
          "AffineComponentPreconditioned": 2, "AffineComponentPreconditionedOnline": 2,
+         "FixedLinearComponent": 2,
          "PnormComponent": 3, "NormalizeComponent": 4, "SoftmaxComponent": 5,
          "SumGroupComponent": 6, "SigmoidComponent": 7, "TanhComponent": 8,
-         "RectifiedLinearComponent": 9}
+         "RectifiedLinearComponent": 9, "SoftHingeComponent": 10, "PowerComponent": 11,
+         "ScaleComponent": 12, "FixedScaleComponent": 13, "FixedBiasComponent": 14,
+         "MaxoutComponent": 15, "PermuteComponent": 16, "DctComponent": 17,
+         "BlockAffineComponent": 18, "BlockAffineComponentPreconditioned": 18}
 
 
 def make_layers(components, struct=NnetLayer):
@@ -183,21 +187,46 @@ def make_layers(components, struct=NnetLayer):
             a.left_context, a.right_context = c["left"], c["right"]
             a.const_dim = c.get("const_dim", 0)
             a.output_dim = (c["input_dim"] - a.const_dim) * (c["left"] + 1 + c["right"]) + a.const_dim
-        elif a.kind == 2:
+        elif a.kind in (2, 18):
             W = np.ascontiguousarray(c["linear"], np.float32)
-            b = np.ascontiguousarray(c["bias"], np.float32)
-            keep += [W, b]
+            keep.append(W)
             a.output_dim, a.input_dim = W.shape
-            a.linear, a.bias = _fp(W), _fp(b)
-        elif t == "PnormComponent":
+            a.linear = _fp(W)
+            if c.get("bias") is not None:
+                b = np.ascontiguousarray(c["bias"], np.float32)
+                keep.append(b)
+                a.bias = _fp(b)
+            if a.kind == 18:
+                a.const_dim = c["num_blocks"]
+                a.input_dim = W.shape[1] * c["num_blocks"]
+        elif t in ("PnormComponent", "MaxoutComponent"):
             a.input_dim, a.output_dim, a.p = c["input_dim"], c["output_dim"], c.get("p", 2.0)
         elif t == "SumGroupComponent":
             s = np.ascontiguousarray(c["sizes"], np.int32)
             keep.append(s)
             a.sizes = _ip(s)
             a.input_dim, a.output_dim = int(s.sum()), len(s)
+        elif t == "PermuteComponent":
+            s = np.ascontiguousarray(c["reorder"], np.int32)
+            keep.append(s)
+            a.sizes = _ip(s)
+            a.input_dim = a.output_dim = len(s)
+        elif t in ("FixedScaleComponent", "FixedBiasComponent"):
+            v = np.ascontiguousarray(c["scales" if t == "FixedScaleComponent" else "bias"], np.float32)
+            keep.append(v)
+            a.bias = _fp(v)
+            a.input_dim = a.output_dim = len(v)
+        elif t == "DctComponent":
+            dct_keep = c.get("dct_keep_dim", 0) or c["dct_dim"]
+            a.input_dim, a.const_dim = c["dim"], c["dct_dim"]
+            a.left_context = 1 if c.get("reorder", False) else 0
+            a.output_dim = dct_keep * (c["dim"] // c["dct_dim"])
         else:
             a.input_dim = a.output_dim = c["dim"]
+            if t == "PowerComponent":
+                a.p = c["power"]
+            elif t == "ScaleComponent":
+                a.p = c["scale"]
     return arr, keep
 
 

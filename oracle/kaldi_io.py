@@ -286,6 +286,56 @@ class Reader:
         elif t == "SumGroupComponent":
             self.expect("<Sizes>"); c["sizes"] = [int(x) for x in self.int_vector(binary)]
             self.expect("<SumGroupComponent>")
+        elif t == "SoftHingeComponent":  # a NonlinearComponent like the ones above
+            self.expect("<Dim>"); c["dim"] = self.int32(binary)
+            self.expect("<ValueSum>"); self.vector(binary)
+            self.expect("<DerivSum>"); self.vector(binary)
+            self.expect("<Count>"); self.float32(binary)
+            self.expect("</%s>" % t)
+        elif t == "MaxoutComponent":  # :481-487
+            self.expect("<InputDim>"); c["input_dim"] = self.int32(binary)
+            self.expect("<OutputDim>"); c["output_dim"] = self.int32(binary)
+            self.expect("</MaxoutComponent>")
+        elif t == "PowerComponent":  # :754-762
+            self.expect("<InputDim>"); c["dim"] = self.int32(binary)
+            self.expect("<OutputDim>"); self.int32(binary)
+            self.expect("<Power>"); c["power"] = self.float32(binary)
+            self.expect("</PowerComponent>")
+        elif t == "ScaleComponent":  # :891-897
+            self.expect("<Dim>"); c["dim"] = self.int32(binary)
+            self.expect("<Scale>"); c["scale"] = self.float32(binary)
+            self.expect("</ScaleComponent>")
+        elif t == "PermuteComponent":  # :2232-2236
+            self.expect("<Reorder>"); c["reorder"] = [int(x) for x in self.int_vector(binary)]
+            self.expect("</PermuteComponent>")
+        elif t == "DctComponent":  # :2892-2918
+            self.expect("<Dim>"); c["dim"] = self.int32(binary)
+            self.expect("<DctDim>"); c["dct_dim"] = self.int32(binary)
+            self.expect("<Reorder>"); c["reorder"] = self.bool_(binary)
+            tok = self.token()
+            if tok == "<DctKeepDim>":
+                c["dct_keep_dim"] = self.int32(binary)
+                tok = self.token()
+            if tok != "</DctComponent>":
+                raise ValueError("expected </DctComponent>, got %s" % tok)
+        elif t == "FixedLinearComponent":  # :2979-2983
+            self.expect("<CuMatrix>"); c["linear"] = self.matrix(binary)
+            self.expect("</FixedLinearComponent>")
+        elif t == "FixedScaleComponent":  # :3134-3138
+            self.expect("<Scales>"); c["scales"] = self.vector(binary)
+            self.expect("</FixedScaleComponent>")
+        elif t == "FixedBiasComponent":  # :3201-3205
+            self.expect("<Bias>"); c["bias"] = self.vector(binary)
+            self.expect("</FixedBiasComponent>")
+        elif t in ("BlockAffineComponent", "BlockAffineComponentPreconditioned"):  # :2045-2055, :2135-2150
+            self.expect("<LearningRate>"); c["lr"] = self.float32(binary)
+            self.expect("<NumBlocks>"); c["num_blocks"] = self.int32(binary)
+            self.expect("<LinearParams>"); c["linear"] = self.matrix(binary)
+            self.expect("<BiasParams>"); c["bias"] = self.vector(binary)
+            if t.endswith("Preconditioned"):
+                self.expect("<Alpha>"); self.float32(binary)
+                self.expect("<IsGradient>"); self.bool_(binary)
+            self.expect("</%s>" % t)
         else:
             raise ValueError("component type %s" % t)
         return c
@@ -554,6 +604,53 @@ def write_component(f, binary, comp):
     elif t == "SumGroupComponent":  # :2343-2350 (closing token has no slash)
         write_token(f, binary, "<Sizes>"); write_int_vector(f, binary, comp["sizes"])
         write_token(f, binary, "<SumGroupComponent>")
+    elif t == "SoftHingeComponent":  # NonlinearComponent :390-404
+        write_token(f, binary, "<Dim>"); write_int32(f, binary, comp["dim"])
+        write_token(f, binary, "<ValueSum>"); write_vector(f, binary, np.zeros(0), double=True)
+        write_token(f, binary, "<DerivSum>"); write_vector(f, binary, np.zeros(0), double=True)
+        write_token(f, binary, "<Count>"); write_double(f, binary, 0.0)
+        write_token(f, binary, "</%s>" % t)
+    elif t == "MaxoutComponent":  # :489-496
+        write_token(f, binary, "<InputDim>"); write_int32(f, binary, comp["input_dim"])
+        write_token(f, binary, "<OutputDim>"); write_int32(f, binary, comp["output_dim"])
+        write_token(f, binary, "</%s>" % t)
+    elif t == "PowerComponent":  # :764-773
+        write_token(f, binary, "<InputDim>"); write_int32(f, binary, comp["dim"])
+        write_token(f, binary, "<OutputDim>"); write_int32(f, binary, comp["dim"])
+        write_token(f, binary, "<Power>"); write_float(f, binary, comp["power"])
+        write_token(f, binary, "</%s>" % t)
+    elif t == "ScaleComponent":  # :882-889
+        write_token(f, binary, "<Dim>"); write_int32(f, binary, comp["dim"])
+        write_token(f, binary, "<Scale>"); write_float(f, binary, comp["scale"])
+        write_token(f, binary, "</%s>" % t)
+    elif t == "PermuteComponent":  # :2238-2243
+        write_token(f, binary, "<Reorder>"); write_int_vector(f, binary, comp["reorder"])
+        write_token(f, binary, "</%s>" % t)
+    elif t == "DctComponent":  # :2877-2890
+        write_token(f, binary, "<Dim>"); write_int32(f, binary, comp["dim"])
+        write_token(f, binary, "<DctDim>"); write_int32(f, binary, comp["dct_dim"])
+        write_token(f, binary, "<Reorder>"); write_bool(f, binary, comp.get("reorder", False))
+        write_token(f, binary, "<DctKeepDim>")
+        write_int32(f, binary, comp.get("dct_keep_dim", 0) or comp["dct_dim"])
+        write_token(f, binary, "</%s>" % t)
+    elif t == "FixedLinearComponent":  # :2972-2977
+        write_token(f, binary, "<CuMatrix>"); write_matrix(f, binary, comp["linear"])
+        write_token(f, binary, "</%s>" % t)
+    elif t == "FixedScaleComponent":  # :3127-3132
+        write_token(f, binary, "<Scales>"); write_vector(f, binary, comp["scales"])
+        write_token(f, binary, "</%s>" % t)
+    elif t == "FixedBiasComponent":  # :3194-3199
+        write_token(f, binary, "<Bias>"); write_vector(f, binary, comp["bias"])
+        write_token(f, binary, "</%s>" % t)
+    elif t in ("BlockAffineComponent", "BlockAffineComponentPreconditioned"):  # :2057-2068, :2153-2168
+        write_token(f, binary, "<LearningRate>"); write_float(f, binary, comp.get("lr", 0.01))
+        write_token(f, binary, "<NumBlocks>"); write_int32(f, binary, comp["num_blocks"])
+        write_token(f, binary, "<LinearParams>"); write_matrix(f, binary, comp["linear"])
+        write_token(f, binary, "<BiasParams>"); write_vector(f, binary, comp["bias"])
+        if t.endswith("Preconditioned"):
+            write_token(f, binary, "<Alpha>"); write_float(f, binary, 4.0)
+            write_token(f, binary, "<IsGradient>"); write_bool(f, binary, False)
+        write_token(f, binary, "</%s>" % t)
     else:
         raise ValueError(t)
 

@@ -12,20 +12,29 @@
  * Paths are relative to /root/reference/src.
  */
 #include <math.h>
+#ifndef M_PI
+#define M_PI 3.14159265358979323846 /* base/kaldi-math.h */
+#endif
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
 enum { K_SPLICE = 1, K_AFFINE = 2, K_PNORM = 3, K_NORMALIZE = 4, K_SOFTMAX = 5,
-       K_SUMGROUP = 6, K_SIGMOID = 7, K_TANH = 8, K_RELU = 9 };
+       K_SUMGROUP = 6, K_SIGMOID = 7, K_TANH = 8, K_RELU = 9, K_SOFTHINGE = 10, K_POWER = 11,
+       K_SCALE = 12, K_FIXED_SCALE = 13, K_FIXED_BIAS = 14, K_MAXOUT = 15, K_PERMUTE = 16,
+       K_DCT = 17, K_BLOCK_AFFINE = 18 };
 
 typedef struct {
-  int32_t kind, input_dim, output_dim, left_context, right_context, const_dim;
-  float p;
-  const float *linear; /* [output_dim x input_dim] */
-  const float *bias;   /* [output_dim] */
-  const int32_t *sizes; /* SUMGROUP */
+  int32_t kind, input_dim, output_dim;
+  int32_t left_context;  /* SPLICE; DCT: reorder_ */
+  int32_t right_context;
+  int32_t const_dim;     /* SPLICE; DCT: dct_dim; BLOCK_AFFINE: num_blocks_ */
+  float p;               /* PNORM / POWER: exponent; SCALE: scale_ */
+  const float *linear; /* AFFINE: [output_dim x input_dim]; BLOCK_AFFINE: the stacked
+                          [output_dim x input_dim / num_blocks] linear_params_ */
+  const float *bias;   /* [output_dim] (NULL: FixedLinear); FIXED_SCALE / FIXED_BIAS: [dim] */
+  const int32_t *sizes; /* SUMGROUP: sizes; PERMUTE: reorder_ */
 } oracle_layer;
 
 /* nnet2/nnet-nnet.cc:39-53  Nnet::LeftContext / RightContext: sums over components
@@ -61,8 +70,88 @@ static void affine(const oracle_layer *l, const float *in, int rows, float *out)
       const float *w = l->linear + (size_t)n * K, *x = in + (size_t)r * K;
       float acc = 0.0f;
       for (int k = 0; k < K; k++) acc += x[k] * w[k];
-      out[(size_t)r * N + n] = acc + l->bias[n];
+      out[(size_t)r * N + n] = l->bias ? acc + l->bias[n] : acc; /* FixedLinear :2948-2953 */
     }
+}
+
+/* nnet2/nnet-component.cc:1907-1939  BlockAffineComponent::Propagate: out = bias rows; block b of
+ * out += block b of in * (rows [b*ob, (b+1)*ob) of linear_params_)^T. */
+static void block_affine(const oracle_layer *l, const float *in, int rows, float *out) {
+  int nb = l->const_dim, ib = l->input_dim / nb, ob = l->output_dim / nb;
+  for (int r = 0; r < rows; r++)
+    for (int b = 0; b < nb; b++)
+      for (int n = 0; n < ob; n++) {
+        const float *w = l->linear + (size_t)(b * ob + n) * ib;
+        const float *x = in + (size_t)r * l->input_dim + b * ib;
+        float acc = 0.0f;
+        for (int k = 0; k < ib; k++) acc += x[k] * w[k];
+        out[(size_t)r * l->output_dim + b * ob + n] = l->bias[b * ob + n] + acc;
+      }
+}
+
+/* nnet2/nnet-component.cc:443-454  MaxoutComponent::Propagate: each output column starts at
+ * -1e20 and takes the max with every column of its group. */
+static void maxout(const oracle_layer *l, const float *in, int rows, float *out) {
+  int gs = l->input_dim / l->output_dim;
+  for (int r = 0; r < rows; r++)
+    for (int j = 0; j < l->output_dim; j++) {
+      float m = (float)-1e20;
+      for (int i = 0; i < gs; i++) {
+        float v = in[(size_t)r * l->input_dim + j * gs + i];
+        if (v > m) m = v;
+      }
+      out[(size_t)r * l->output_dim + j] = m;
+    }
+}
+
+/* nnet2/nnet-component.cc:2262-2270  PermuteComponent::Propagate: reverse_reorder[reorder[i]] = i,
+ * out(r, c) = in(r, reverse_reorder[c])  (CopyCols). */
+static void permute(const oracle_layer *l, const float *in, int rows, float *out) {
+  int D = l->input_dim;
+  int *rev = (int *)malloc(D * sizeof(int));
+  for (int i = 0; i < D; i++) rev[l->sizes[i]] = i;
+  for (int r = 0; r < rows; r++)
+    for (int c = 0; c < D; c++) out[(size_t)r * D + c] = in[(size_t)r * D + rev[c]];
+  free(rev);
+}
+
+/* nnet2/nnet-component.cc:2776-2800  DctComponent::Reorder on one row of `cols` columns: a zeroed
+ * temporary of the row's length, temp(j * block_size_out + b) = row(b * block_size_in + j) for
+ * b < block_size_out, j < block_size_in, then the row becomes the temporary. */
+static void dct_reorder(float *row, int cols, int block_size_in, int block_size_out) {
+  float *temp = (float *)calloc(cols, sizeof(float));
+  for (int b = 0; b < block_size_out; b++)
+    for (int j = 0; j < block_size_in; j++) temp[j * block_size_out + b] = row[b * block_size_in + j];
+  memcpy(row, temp, cols * sizeof(float));
+  free(temp);
+}
+
+/* nnet2/nnet-component.cc:2802-2830  DctComponent::Propagate with the matrix of
+ * matrix/matrix-functions.cc:592-608 (float normalizer times a double cosine, stored as float;
+ * only the first dct_keep_dim rows are built, :2744-2756). */
+static void dct(const oracle_layer *l, const float *in, int rows, float *out) {
+  int dim = l->input_dim, N = l->const_dim, chunks = dim / N, K = l->output_dim / chunks;
+  float *M = (float *)malloc((size_t)K * N * sizeof(float));
+  float normalizer = (float)sqrt(1.0 / (float)N);
+  for (int j = 0; j < N; j++) M[j] = normalizer;
+  normalizer = (float)sqrt(2.0 / (float)N);
+  for (int k = 1; k < K; k++)
+    for (int n = 0; n < N; n++) M[(size_t)k * N + n] = (float)(normalizer * cos((double)M_PI / N * (n + 0.5) * k));
+  float *tmp = (float *)malloc(dim * sizeof(float));
+  for (int r = 0; r < rows; r++) {
+    memcpy(tmp, in + (size_t)r * dim, dim * sizeof(float));
+    if (l->left_context) dct_reorder(tmp, dim, dim / N, K);
+    float *o = out + (size_t)r * l->output_dim;
+    for (int ch = 0; ch < chunks; ch++)
+      for (int k = 0; k < K; k++) {
+        float acc = 0.0f;
+        for (int n = 0; n < N; n++) acc += tmp[ch * N + n] * M[(size_t)k * N + n];
+        o[ch * K + k] = acc;
+      }
+    if (l->left_context) dct_reorder(o, l->output_dim, K, dim / N);
+  }
+  free(tmp);
+  free(M);
 }
 
 /* matrix/kaldi-matrix.cc:2451-2459 GroupPnorm -> matrix/kaldi-vector.cc:529-566 Norm(p). */
@@ -151,11 +240,30 @@ static void sumgroup(const oracle_layer *l, const float *in, int rows, float *ou
   }
 }
 
+/* matrix/kaldi-vector.cc:496-525 ApplyPowAbs(power, include_sign = false) on one element; the
+ * power == 1 branch is not chained to the others, so such an element also takes the last one. */
+static float pow_abs(float x, float power) {
+  if (power == 1.0f) x = fabsf(x);
+  if (power == 2.0f) return x * x;
+  if (power == 0.5f) return sqrtf(fabsf(x));
+  if (power < 0.0f) return x == 0.0f ? 0.0f : (float)pow(fabsf(x), power);
+  return (float)pow(fabsf(x), power);
+}
+
 /* matrix/kaldi-vector.cc:937-951 Sigmoid, :899-913 Tanh (non-MKL branches: double
- * literals promote the arithmetic to double), nnet-component.cc:782-788 ReLU. */
-static void elementwise(int kind, const float *in, size_t n, float *out) {
+ * literals promote the arithmetic to double), nnet-component.cc:782-788 ReLU,
+ * matrix/kaldi-matrix.cc:2434-2448 SoftHinge (Exp and Log1p of base/kaldi-math.h: expf, log1pf),
+ * nnet-component.cc:731-737 Power, :844-850 Scale, :3103-3109 FixedScale (MulColsVec),
+ * :3171-3177 FixedBias (AddVecToRows). */
+static void elementwise(const oracle_layer *l, const float *in, size_t n, float *out) {
+  int kind = l->kind;
   for (size_t i = 0; i < n; i++) {
     float x = in[i];
+    if (kind == K_SOFTHINGE) { out[i] = x > 10.0f ? x : log1pf(expf(x)); continue; }
+    if (kind == K_POWER) { out[i] = pow_abs(x, l->p); continue; }
+    if (kind == K_SCALE) { out[i] = x * l->p; continue; }
+    if (kind == K_FIXED_SCALE) { out[i] = x * l->bias[i % l->input_dim]; continue; }
+    if (kind == K_FIXED_BIAS) { out[i] = x + l->bias[i % l->input_dim]; continue; }
     if (kind == K_SIGMOID) {
       if (x > 0.0f) x = (float)(1.0 / (1.0 + expf(-x)));
       else { float ex = expf(x); x = (float)(ex / (ex + 1.0)); }
@@ -203,7 +311,11 @@ int oracle_nnet_compute(const oracle_layer *L, int n, const float *priors, int n
       case K_NORMALIZE: normalize(l, cur, rows, next); break;
       case K_SOFTMAX: softmax(l, cur, rows, next); break;
       case K_SUMGROUP: sumgroup(l, cur, rows, next); break;
-      default: elementwise(l->kind, cur, (size_t)rows * dim, next); break;
+      case K_BLOCK_AFFINE: block_affine(l, cur, rows, next); break;
+      case K_MAXOUT: maxout(l, cur, rows, next); break;
+      case K_PERMUTE: permute(l, cur, rows, next); break;
+      case K_DCT: dct(l, cur, rows, next); break;
+      default: elementwise(l, cur, (size_t)rows * dim, next); break;
     }
     free(cur);
     cur = next;

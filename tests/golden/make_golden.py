@@ -14,6 +14,10 @@ Files written (all small):
   gmm_b.mdl  gmm_b_feats.ark  gmm_b_likes.ark  dim 13, one very large pdf (split over waves on the GPU)
   nnet_a.mdl nnet_a_feats.ark nnet_a_post.ark nnet_a_log.ark nnet_a_loglikes.ark nnet_a_post_nopad.ark
   nnet_b.mdl nnet_b_feats.ark nnet_b_post.ark  sigmoid / tanh / relu / mix-up sum-group network
+  nnet_c.mdl nnet_c_feats.ark nnet_c_post.ark nnet_c_post_nopad.ark   Dct, FixedScale, FixedBias, SoftHinge,
+                                               Permute, FixedLinear, Maxout, Scale, Power, BlockAffine
+  nnet_d.mdl nnet_d_feats.ark nnet_d_post.ark  Dct with <Reorder> (whole and truncated), the Power branches
+               (python tests/golden/make_golden.py nnet_cd   regenerates these two only)
   cm_feats.ark  cm_feats_expanded.ark          CompressedMatrix archive and its expansion
   gsel.mdl gsel_feats.ark gsel_top5.txt        DiagGmm::GaussianSelection, 5 of 64 per frame
   xf_feats.ark xf_mats.ark                     13-dim features; "lda" 40x92, "lin" 40x91, "fmllr" 40x41
@@ -74,10 +78,61 @@ def nnet_case(tag, comps, priors, feats_items, full=True):
         oracle.ref_driver("nnet-compute", mdl, fe, "ark:" + path(tag + "_post_nopad.ark"), "0", "0")
 
 
+def nnet_cd_cases():
+    """The components outside the p-norm recipe, two small networks (own seeds, so adding to
+    them leaves every other fixture as it is)."""
+    rng = np.random.default_rng(4040)
+
+    def aff(kind, i, o, **kw):
+        return dict(type=kind, linear=(rng.standard_normal((o, i)) / np.sqrt(i)).astype(np.float32),
+                    bias=(0.5 * rng.standard_normal(o)).astype(np.float32), **kw)
+
+    comps_c = [
+        dict(type="SpliceComponent", input_dim=10, left=1, right=1, const_dim=0),
+        dict(type="DctComponent", dim=30, dct_dim=10, reorder=False, dct_keep_dim=6),
+        dict(type="FixedScaleComponent", scales=(0.5 + rng.random(18)).astype(np.float32)),
+        dict(type="FixedBiasComponent", bias=rng.standard_normal(18).astype(np.float32)),
+        aff("AffineComponent", 18, 24), dict(type="SoftHingeComponent", dim=24),
+        dict(type="PermuteComponent", reorder=[int(x) for x in rng.permutation(24)]),
+        dict(type="FixedLinearComponent", linear=(rng.standard_normal((24, 24)) / 5).astype(np.float32)),
+        dict(type="MaxoutComponent", input_dim=24, output_dim=12),
+        dict(type="ScaleComponent", dim=12, scale=0.7),
+        dict(type="PowerComponent", dim=12, power=1.5),
+        dict(type="BlockAffineComponent", num_blocks=4,
+             linear=(rng.standard_normal((20, 3)) / 2).astype(np.float32),
+             bias=(0.3 * rng.standard_normal(20)).astype(np.float32)),
+        dict(type="SoftmaxComponent", dim=20),
+    ]
+    pri_c = rng.dirichlet(np.ones(20)).astype(np.float32)
+    feats_c = [("c1", (4 * rng.standard_normal((37, 10))).astype(np.float32)),  # some SoftHinge inputs beyond 10
+               ("c2", rng.standard_normal((3, 10)).astype(np.float32))]
+    nnet_case("nnet_c", comps_c, pri_c, feats_c, full=False)
+    oracle.ref_driver("nnet-compute", path("nnet_c.mdl"), "ark:" + path("nnet_c_feats.ark"),
+                      "ark:" + path("nnet_c_post_nopad.ark"), "0", "0")
+    comps_d = [
+        dict(type="SpliceComponent", input_dim=8, left=2, right=2, const_dim=0),
+        dict(type="DctComponent", dim=40, dct_dim=5, reorder=True),
+        dict(type="DctComponent", dim=40, dct_dim=8, reorder=True, dct_keep_dim=3),
+        aff("AffineComponent", 15, 16), dict(type="RectifiedLinearComponent", dim=16),
+        dict(type="PowerComponent", dim=16, power=-0.5),  # exact zeros behind the ReLU stay zero
+        aff("FixedAffineComponent", 16, 16),
+        dict(type="PowerComponent", dim=16, power=2.0), dict(type="PowerComponent", dim=16, power=0.5),
+        dict(type="PowerComponent", dim=16, power=1.0),
+        dict(type="BlockAffineComponentPreconditioned", num_blocks=2,
+             linear=(rng.standard_normal((8, 8)) / 3).astype(np.float32),
+             bias=(0.3 * rng.standard_normal(8)).astype(np.float32)),
+        dict(type="SoftmaxComponent", dim=8),
+    ]
+    pri_d = rng.dirichlet(np.ones(8)).astype(np.float32)
+    nnet_case("nnet_d", comps_d, pri_d, [("d1", rng.standard_normal((29, 8)).astype(np.float32))], full=False)
+
+
 def main():
     if not oracle.have_ref():
         sys.exit("oracle/_ref/ref_driver is not built (run oracle/build_ref.sh in a container "
                  "that has /root/reference)")
+    if sys.argv[1:] == ["nnet_cd"]:
+        return nnet_cd_cases()
     # gmm_a: an rm_tri1-like slice (D=39), 30 pdfs / 200 Gaussians, two utterances.
     a = synth.make_gmm(39, 30, 200, seed=4001)
     fa = [("utt1", synth.make_feats(a, 50, seed=4002)), ("utt2", synth.make_feats(a, 7, seed=4003))]
@@ -115,6 +170,7 @@ def main():
     ]
     pri_b = np.random.default_rng(5).dirichlet(np.ones(20)).astype(np.float32)
     nnet_case("nnet_b", comps_b, pri_b, [("m", rng.standard_normal((33, 10)).astype(np.float32))], full=False)
+    nnet_cd_cases()
     # Gaussian selection (DiagGmm::GaussianSelection) on a 64-component mixture.
     ubm = synth.make_gmm(20, 1, 64, seed=4020)
     write_am("gsel.mdl", ubm)

@@ -286,6 +286,31 @@ def test_nnet_am_compute_binary(nnet_files, apply_log, pad):
             assert (l.argmax(1) == want.argmax(1)).mean() >= 0.9999
 
 
+@pytest.mark.parametrize("tag", ["nnet_c", "nnet_d"])
+@pytest.mark.parametrize("binary", [True, False])
+def test_nnet_am_compute_reads_every_forward_component(tmp_path, tag, binary):
+    """The model reader of the binaries on the networks that hold Dct, FixedScale, FixedBias,
+    SoftHinge, Permute, FixedLinear, Maxout, Scale, Power and BlockAffine components, in the
+    binary and the text form, against the posteriors the reference computed for them."""
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    data = open(os.path.join(golden, tag + ".mdl"), "rb").read()
+    r = kio.Reader(data)
+    comps, priors = r.am_nnet(r.read_binary_marker())
+    with kio.open_out(str(tmp_path / "final.mdl"), binary) as f:
+        topo, triples = kio.make_transition_model(len(priors))
+        kio.write_transition_model(f, binary, topo, triples)
+        kio.write_am_nnet(f, binary, comps, priors)
+    out = str(tmp_path / "post.ark")
+    run("nnet-am-compute", "--apply-log=false", str(tmp_path / "final.mdl"),
+        "ark:" + os.path.join(golden, tag + "_feats.ark"), "ark:" + out)
+    got = dict(kio.read_ark(out))
+    want = dict(kio.read_ark(os.path.join(golden, tag + "_post.ark")))
+    assert set(got) == set(want)
+    for key in want:
+        assert got[key].shape == want[key].shape
+        assert np.abs(got[key] - want[key]).max() <= 1e-5
+
+
 def test_nnet_am_compute_several_workers_same_archive(nnet_files, tmp_path):
     """As for gmm-compute-likes: three workers on one GPU write the bytes one worker writes."""
     d, comps, priors, _, _ = nnet_files

@@ -85,6 +85,52 @@ def test_nnet_other_components_vs_golden(amlike_device):
         assert np.abs(got - want[key]).max() <= 1e-5
 
 
+@pytest.mark.parametrize("tag", ["nnet_c", "nnet_d"])
+def test_nnet_remaining_components_vs_golden(amlike_device, tag):
+    """Dct (plain, reordered, truncated), FixedScale, FixedBias, SoftHinge, Permute, FixedLinear,
+    Maxout, Scale, Power and BlockAffine: the reference's posteriors, 1e-5 absolute, for one
+    utterance at a time and for all of them in one batch."""
+    import torch
+    comps, priors = load_am_nnet(tag + ".mdl")
+    net = nnet.AmNnet(comps, priors)
+    want = dict(load_ark(tag + "_post.ark"))
+    items = load_ark(tag + "_feats.ark")
+    for key, feats in items:
+        got = net.Compute(feats, pad_input=True, mode=nnet.POSTERIORS)
+        assert got.shape == want[key].shape
+        assert np.abs(got - want[key]).max() <= 1e-5
+        assert (got.argmax(1) == want[key].argmax(1)).all()
+    if tag == "nnet_c":
+        nopad = dict(load_ark(tag + "_post_nopad.ark"))
+        for key, feats in items:
+            got = net.Compute(feats, pad_input=False, mode=nnet.POSTERIORS)
+            assert got.shape == nopad[key].shape
+            assert np.abs(got - nopad[key]).max() <= 1e-5
+    lens = np.array([f.shape[0] for _, f in items], np.int32)
+    allf = torch.from_numpy(np.concatenate([f for _, f in items])).cuda()
+    out = torch.empty((int(lens.sum()), net.OutputDim()), device="cuda")
+    net.ComputeBatchDevice(allf.data_ptr(), allf.shape[1], lens, out.data_ptr(), out.shape[1],
+                           pad_input=True, mode=nnet.POSTERIORS)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.abs(got - np.concatenate([want[k] for k, _ in items])).max() <= 1e-5
+    net.close()
+
+
+def test_nnet_create_refuses_malformed_components(amlike_device):
+    def one(c, dim):
+        return [dict(type="SpliceComponent", input_dim=dim, left=0, right=0), c]
+    bad = [
+        one(dict(type="PermuteComponent", reorder=[0, 1, 1, 3]), 4),           # not a permutation
+        one(dict(type="MaxoutComponent", input_dim=10, output_dim=3), 10),     # 3 does not divide 10
+        one(dict(type="DctComponent", dim=12, dct_dim=5, reorder=False), 12),  # 5 does not divide 12
+        one(dict(type="DctComponent", dim=12, dct_dim=4, reorder=False, dct_keep_dim=6), 12),
+    ]
+    for comps in bad:
+        with pytest.raises(Exception):
+            nnet.AmNnet(comps, None)
+
+
 def test_gaussian_selection_vs_golden_and_oracle(amlike_device):
     import oracle
     from golden_util import load_gselect

@@ -95,6 +95,25 @@ def test_nnet_other_components_vs_golden():
         np.testing.assert_allclose(got.sum(1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("tag,nopad", [("nnet_c", True), ("nnet_d", False)])
+def test_nnet_remaining_components_vs_golden(tag, nopad):
+    """Dct (plain, reordered, truncated), FixedScale, FixedBias, SoftHinge, Permute, FixedLinear,
+    Maxout, Scale, Power (every branch of ApplyPowAbs) and BlockAffine against the reference."""
+    comps, priors = load_am_nnet(tag + ".mdl")
+    want = dict(load_ark(tag + "_post.ark"))
+    for key, feats in load_ark(tag + "_feats.ark"):
+        got = oracle.nnet_compute(comps, priors, feats, pad_input=True, mode=0)
+        assert got.shape == want[key].shape
+        assert np.abs(got - want[key]).max() <= ORACLE_TOL
+    if nopad:
+        want = dict(load_ark(tag + "_post_nopad.ark"))
+        assert want["c2"].shape[0] == 1  # 3 frames, one of context on each side
+        for key, feats in load_ark(tag + "_feats.ark"):
+            got = oracle.nnet_compute(comps, priors, feats, pad_input=False, mode=0)
+            assert got.shape == want[key].shape
+            assert np.abs(got - want[key]).max() <= ORACLE_TOL
+
+
 def test_log_sum_exp_edge_cases():
     L = oracle.load()
     import ctypes
