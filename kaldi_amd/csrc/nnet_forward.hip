@@ -1195,6 +1195,7 @@ __device__ __forceinline__ void static_for(F &&f) {  // f(integral_constant<int,
 }
 #ifdef AMLIKE_OUT_STAMPS  // diagnostic build: clock ticks of the two sweeps of job 0, printed per launch
 __device__ unsigned long long g_out_stamps[8];
+__device__ unsigned long long g_out_stalls[16];  // per wave: sweep 1 wait, barrier; sweep 2 wait, barrier
 #endif
 struct OutJobs {
   int nbig;    // jobs of 256 rows
@@ -1427,6 +1428,9 @@ __global__ void __launch_bounds__(256, 1)
     // all younger than the request and the wait at the end of the step (all but the newest
     // loads and stores) does not wait for any of them.
     constexpr int kRequestKs = 0;
+#ifdef AMLIKE_OUT_STAMPS
+    unsigned long long stall[4] = {0, 0, 0, 0};  // ticks in the end-of-step wait and barrier, per sweep
+#endif
     auto step = [&](int seq, f32x16 (&acc_new)[FT], const f32x16 (&acc_old)[FT], auto kind_tag,
                     int old_n0, bool stores_counted = false) __attribute__((always_inline)) {
       constexpr int kKind = decltype(kind_tag)::value;
@@ -1497,11 +1501,22 @@ __global__ void __launch_bounds__(256, 1)
       // tile seq + 2 (requested kLead - 1.5 steps ago) has landed; every wave has finished
       // reading tile seq
       if constexpr (PREC == 1) mfma_result_gap();
+#ifdef AMLIKE_OUT_STAMPS
+      const unsigned long long w0 = __builtin_readcyclecounter();
+#endif
       // (stores_counted: this step and the kLead - 2 before it each issued all their 4 FT stores,
       // which are younger than the request waited for and need not have finished)
       if (kKind == 2 && stores_counted) wait_vector_memory_but<(kLead - 2) * (kMine + 1) + (kLead - 1) * 4 * FT>();
       else wait_vector_memory_but<(kLead - 2) * (kMine + 1)>();
+#ifdef AMLIKE_OUT_STAMPS
+      const unsigned long long w1 = __builtin_readcyclecounter();
+#endif
       barrier_only();
+#ifdef AMLIKE_OUT_STAMPS
+      const unsigned long long w2 = __builtin_readcyclecounter();
+      stall[seq >= ntile ? 2 : 0] += w1 - w0;
+      stall[seq >= ntile ? 3 : 1] += w2 - w1;
+#endif
     };
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
@@ -1568,6 +1583,10 @@ __global__ void __launch_bounds__(256, 1)
       g_out_stamps[2] = r1 - r0;
       g_out_stamps[3] = __builtin_amdgcn_s_memrealtime() - r1;
       g_out_stamps[4] = ntile;
+    }
+    if ((int)blockIdx.x == jobs.lead && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g_out_stalls[w * 4 + i] = stall[i];
     }
 #endif
   };
@@ -2010,6 +2029,7 @@ struct Stage {
   // 2: fp16x2 on trial (weights fit, input range unknown): d_wpo_safe / d_wpn_safe hold the
   //    bf16x3 images the fallback kernels read
   int f16 = 0;
+  bool normalised_input = false;  // the stage reads the output of a NormalizeComponent
   uint4 *d_wpo_safe = nullptr, *d_wpn_safe = nullptr;
   std::vector<float> h_w, h_b;  // host copies kept until the next component is known
   float *d_bias = nullptr;
@@ -2030,6 +2050,7 @@ struct amlike_nnet {
   bool gemm_inline_split = false;  // AMLIKE_NNET_GEMM=inline: bf16x3 GEMM that splits X in its k-loop
   int pnorm_rows = 1;  // AMLIKE_NNET_PNORM_ROWS=0: never the row-stationary affine + p-norm kernel (A/B aid)
   int pnorm_xcd_order = 1;  // AMLIKE_NNET_PNORM_XCD=0: launch-order block mapping in the affine + p-norm kernel (A/B aid)
+  int collapse = 1;  // AMLIKE_NNET_COLLAPSE=0: an affine stage right behind another stays a stage of its own (A/B aid)
   float *d_log_priors = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // submit / wait: the copies out, behind the kernels
@@ -2060,18 +2081,20 @@ int LaunchPlaneGemmBf16x3(const void *xp, size_t xplane, const void *wp, size_t 
   return AMLIKE_OK;
 }
 
+static void FreeStage(Stage &s) {
+  (void)hipFree(s.d_w);
+  (void)hipFree(s.d_wp);
+  (void)hipFree(s.d_wpo);
+  (void)hipFree(s.d_wpn);
+  (void)hipFree(s.d_wpr);
+  (void)hipFree(s.d_wpo_safe);
+  (void)hipFree(s.d_wpn_safe);
+  (void)hipFree(s.d_bias);
+  (void)hipFree(s.d_begins);
+}
+
 static void FreeNnet(amlike_nnet *n) {
-  for (Stage &s : n->stages) {
-    (void)hipFree(s.d_w);
-    (void)hipFree(s.d_wp);
-    (void)hipFree(s.d_wpo);
-    (void)hipFree(s.d_wpn);
-    (void)hipFree(s.d_wpr);
-    (void)hipFree(s.d_wpo_safe);
-    (void)hipFree(s.d_wpn_safe);
-    (void)hipFree(s.d_bias);
-    (void)hipFree(s.d_begins);
-  }
+  for (Stage &s : n->stages) FreeStage(s);
   (void)hipFree(n->d_log_priors);
   (void)hipFree(n->d_flags);
   n->ws_a.Free();
@@ -2276,6 +2299,12 @@ static int LaunchOutSoftmax(const Stage &s, const uint4 *xp, size_t xplane, cons
     if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_out_stamps), sizeof(hs)) == hipSuccess && hs[4])
       fprintf(stderr, "out+softmax job 0: sweep 1 %.0f ticks/tile (%.3f us), sweep 2 %.0f ticks/tile (%.3f us), %llu tiles\n",
               (double)hs[0] / hs[4], hs[2] * 0.01 / hs[4], (double)hs[1] / hs[4], hs[3] * 0.01 / hs[4], hs[4]);
+    unsigned long long sl[16];
+    if (hipMemcpyFromSymbol(sl, HIP_SYMBOL(g_out_stalls), sizeof(sl)) == hipSuccess && hs[4])
+      for (int w = 0; w < 4; ++w)
+        fprintf(stderr, "out+softmax job 0 wave %d, ticks/tile at the end of a step: sweep 1 wait %.0f barrier %.0f, sweep 2 wait %.0f barrier %.0f\n",
+                w, (double)sl[4 * w] / hs[4], (double)sl[4 * w + 1] / hs[4], (double)sl[4 * w + 2] / hs[4],
+                (double)sl[4 * w + 3] / hs[4]);
   }
 #endif
   return AMLIKE_OK;
@@ -2800,6 +2829,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
   }
   if (const char *e = getenv("AMLIKE_NNET_PNORM_XCD")) n->pnorm_xcd_order = e[0] != '0';
   if (const char *e = getenv("AMLIKE_NNET_PNORM_ROWS")) n->pnorm_rows = e[0] != '0';
+  if (const char *e = getenv("AMLIKE_NNET_COLLAPSE")) n->collapse = e[0] != '0';
   n->input_dim = comps[0].input_dim;
   int dim = comps[0].input_dim;
   int rc = AMLIKE_OK;
@@ -2855,10 +2885,48 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
           rc = AMLIKE_EINVAL;
           break;
         }
-        s.Kp = RoundUp(c.input_dim, 16);
+        // An affine stage right behind another one (FixedAffine then Affine: the LDA-like input
+        // transform of the p-norm recipes) becomes one stage, W = W2 W1, b = W2 b1 + b2, as
+        // Nnet::Collapse does for nnet-am-copy --collapse (nnet2/nnet-nnet.cc:624-663,
+        // nnet2/nnet-component.cc:1292-1306), when that costs no more arithmetic per frame.
+        // Sums in double, rounded to float once.
+        int in_dim = c.input_dim;
+        s.normalised_input = i > 0 && comps[i - 1].kind == AMLIKE_NORMALIZE;
+        std::vector<float> both_w, both_b;
+        if (n->collapse && !n->stages.empty()) {
+          Stage &pv = n->stages.back();
+          if (pv.kind == AMLIKE_AFFINE && !pv.fuse_gs && !pv.h_w.empty() && pv.out_dim == c.input_dim &&
+              (int64_t)c.output_dim * pv.in_dim <=
+                  (int64_t)c.output_dim * c.input_dim + (int64_t)pv.out_dim * pv.in_dim) {
+            in_dim = pv.in_dim;
+            both_w.resize((size_t)c.output_dim * in_dim);
+            both_b.resize(c.output_dim);
+            std::vector<double> row(in_dim);
+            for (int o = 0; o < c.output_dim; ++o) {
+              std::fill(row.begin(), row.end(), 0.0);
+              double bsum = lin_bias[o];
+              const float *w2 = lin + (size_t)o * c.input_dim;
+              for (int m = 0; m < c.input_dim; ++m) {
+                const double f = w2[m];
+                const float *w1 = &pv.h_w[(size_t)m * pv.Kp];
+                for (int k = 0; k < in_dim; ++k) row[k] += f * w1[k];
+                bsum += f * pv.h_b[m];
+              }
+              for (int k = 0; k < in_dim; ++k) both_w[(size_t)o * in_dim + k] = (float)row[k];
+              both_b[o] = (float)bsum;
+            }
+            s.normalised_input = pv.normalised_input;
+            FreeStage(pv);
+            n->stages.pop_back();
+            lin = both_w.data();
+            lin_bias = both_b.data();
+            s.in_dim = in_dim;
+          }
+        }
+        s.Kp = RoundUp(in_dim, 16);
         std::vector<float> w((size_t)c.output_dim * s.Kp, 0.0f);
         for (int r = 0; r < c.output_dim; ++r)
-          memcpy(&w[(size_t)r * s.Kp], lin + (size_t)r * c.input_dim, c.input_dim * sizeof(float));
+          memcpy(&w[(size_t)r * s.Kp], lin + (size_t)r * in_dim, in_dim * sizeof(float));
         s.h_w = w;
         s.h_b.assign(lin_bias, lin_bias + c.output_dim);
         std::vector<uint16_t> wp(3 * w.size());
@@ -2874,8 +2942,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
           for (float v : w) wmax = std::max(wmax, std::fabs(v));
           for (int r = 0; r < c.output_dim; ++r) wmax = std::max(wmax, std::fabs(lin_bias[r]));
           const bool w_ok = std::isfinite(wmax) && wmax <= 1024.0f && !getenv("AMLIKE_NNET_NOF16");
-          const bool normalised_input = i > 0 && comps[i - 1].kind == AMLIKE_NORMALIZE;
-          s.f16 = !w_ok ? 0 : normalised_input ? 1 : (getenv("AMLIKE_NNET_NOF16TRY") ? 0 : 2);
+          s.f16 = !w_ok ? 0 : s.normalised_input ? 1 : (getenv("AMLIKE_NNET_NOF16TRY") ? 0 : 2);
         }
         std::vector<uint16_t> wpo = BuildPlaneWeights(w, s.Kp, c.output_dim, s.f16);
         hipError_t e = hipMalloc(&s.d_w, w.size() * sizeof(float));
