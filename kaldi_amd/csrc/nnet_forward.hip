@@ -1883,6 +1883,348 @@ __global__ void __launch_bounds__(512, 2)
 #endif
 }
 
+// Output layer and softmax with the skeleton of nnet_pnorm_rows_kernel: 8 waves of 32 rows each,
+// two to a SIMD, X fragments resident, W tiles of 32 units streamed through the LDS ring, the
+// accumulators in the ordinary registers, counted LDS waits, the bias as a k column (the
+// units that pad the last tile carry a bias of -60000: no share in any row's sum).  Two sweeps
+// over the units as in nnet_out_softmax_kernel; what differs is how the finished values leave:
+//   sweep 1  W fragment as the A operand, X fragment as B: a lane holds 16 units of ITS row, the
+//            running (max, sum of exponentials) never cross lanes;
+//   sweep 2  the same registers the other way round (X as A, W as B): a lane holds ONE unit for 16
+//            rows, so a 4-byte store per accumulator register writes, over the half-wave, the 32
+//            consecutive units of a row (128 bytes) -- no staging through LDS, no 16 log priors
+//            per lane (one), and the LDS the staging tiles took holds a fifth W tile.
+// Rows' log Z pass from the first layout to the second through 32 floats of LDS per wave.
+__host__ __device__ constexpr int OutRowsRing(int KS) {
+  const int tile = 2 * 2 * KS * 32 * 16, room = 160 * 1024 - 8 * 256 - 8 * 128;
+  return room / tile >= 5 ? 5 : room / tile;
+}
+// `acc += a . b` with the a operand in the accumulation half of the register file and b, like
+// the accumulator, in the ordinary one (mfma_f16_asm_vacc with the operands' places exchanged).
+template <bool FIRST, class BFrag>
+__device__ __forceinline__ void mfma_f16_asm_vacc_swapped(f32x16 &acc, const bf16x8_t &a, const BFrag &b) {
+#if __HIP_DEVICE_COMPILE__
+  if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+#endif
+}
+// Stores `val` at base + off: base wave-uniform (scalar registers), off a byte offset per lane.
+__device__ __forceinline__ void store_f32_at(const char *base, unsigned off, float val) {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(val), "s"(base));
+#endif
+}
+__device__ __forceinline__ void lds_hidden_read32(float &v, unsigned addr) {  // valid after lds_hidden_wait32
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+#endif
+}
+__device__ __forceinline__ void lds_hidden_wait32(float &v) {
+#if __HIP_DEVICE_COMPILE__
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+#endif
+}
+#ifdef AMLIKE_OUTROWS_STAMPS  // diagnostic build: clock ticks of the two sweeps of the first 256-row job
+__device__ unsigned long long g_outrows_stamps[8];
+#endif
+
+template <int KS, bool LOGM>
+__global__ void __launch_bounds__(512, 2)
+    nnet_out_rows_kernel(const uint4 *__restrict__ Xp, size_t xplane, const uint4 *__restrict__ Wp,
+                         size_t wplane, int Npad, const float *__restrict__ logprior_pad,
+                         float *__restrict__ Y, int ldy, int M, int N, int post, float scale, OutJobs jobs) {
+  constexpr int NPL = 2, NPROD = 3, NW = 8;
+  constexpr int kTileU4 = NPL * 2 * KS * 32;  // uint4 per staged W tile: [plane][octet][32 units]
+  constexpr int kRing = OutRowsRing(KS), kLead = kRing - 1;  // tile seq + kLead is requested in step seq
+  constexpr int kSideRing = 8;  // the 32 log priors of a tile (twice, one copy per half-wave), kept longer than the tile
+  static_assert(kRing >= 4, "the W ring needs four tiles");
+  constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
+  uint4 *s_w = reinterpret_cast<uint4 *>(smem_q);
+  float *s_lp = reinterpret_cast<float *>(s_w + kRing * kTileU4);
+  float *s_lz = s_lp + kSideRing * 64;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  int row0, nrows;
+  const int b = blockIdx.x;
+  if (b >= jobs.lead && b < jobs.lead + jobs.nbig) {
+    row0 = (b - jobs.lead) * 256;
+    nrows = 256;
+  } else {
+    row0 = jobs.nbig * 256 + (b < jobs.lead ? b : b - jobs.nbig) * jobs.small;
+    nrows = min(jobs.small, M - row0);
+  }
+  if (nrows <= 0) return;
+  const int ntile = Npad >> 5;
+  const int total = 2 * ntile;  // W tiles to stream: both sweeps
+  const bool has_prior = (post & kPostPrior) != 0;
+  // (without priors the side ring is filled from the start of W: the values are read and dropped)
+  const float *lp_src = has_prior ? logprior_pad : reinterpret_cast<const float *>(Wp);
+
+  // The W stream, as in nnet_pnorm_rows_kernel: pieces of 1 KiB dealt round-robin to the 8 waves,
+  // kMine per wave and tile, plus the tile's log priors (256 bytes, every wave the same ones):
+  // kMine + 1 vector-memory loads per wave and tile.
+  constexpr int kPieces = NPL * KS, kMine = (kPieces + NW - 1) / NW;
+  const int rot = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 7u) % (unsigned)(NW * kMine)));
+  unsigned piece_off[kMine];  // bytes from Wp + 512 tile
+  int piece_at[kMine];        // uint4 index inside a ring slot
+#pragma unroll
+  for (int i = 0; i < kMine; ++i) {
+    const int piece = min((w + NW * i + rot) % (NW * kMine), kPieces - 1);
+    const int q = piece / KS, op = piece - q * KS;  // plane, octet pair
+    piece_off[i] = (unsigned)(((size_t)q * wplane + (size_t)(2 * op + h) * Npad + li) * 16);
+    piece_at[i] = __builtin_amdgcn_readfirstlane(piece * 64);
+  }
+  auto request = [&](int seq) __attribute__((always_inline)) {
+    const int tile = seq % ntile;
+    const char *src0 = reinterpret_cast<const char *>(Wp) + (size_t)tile * 512;
+    uint4 *dst = s_w + (seq % kRing) * kTileU4;
+#pragma unroll
+    for (int i = 0; i < kMine; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + piece_off[i]),
+                                       (__attribute__((address_space(3))) void *)(dst + piece_at[i]), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(lp_src + (tile << 5) + li),
+                                     (__attribute__((address_space(3))) void *)(s_lp + (seq % kSideRing) * 64), 4, 0, 0);
+  };
+
+  constexpr int NMF = KS * NPROD;  // matrix instructions per W tile
+  constexpr int kSkip = 3;         // matrix instructions of a step issued before the previous tile's values are read
+  const int rl = w * 32 + li;      // this lane's row within the job (sweep 1)
+  bf16x8_t xf[KS][NPL];
+  {
+    const size_t r = (size_t)min(row0 + rl, M - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+        xf[ks][q] = __builtin_bit_cast(bf16x8_t, Xp[(size_t)q * xplane + (size_t)(2 * ks + h) * M + r]);
+  }
+  static_for<kLead>([&](auto t) __attribute__((always_inline)) { request(decltype(t)::value); });
+
+  // One accumulator chain per tile (the register budget of two waves per SIMD, 128 ordinary
+  // registers, does not hold two): a matrix instruction that continues the chain of the one just
+  // before it issues a few cycles late when its wave is alone, and in the other wave's shadow otherwise.
+  typedef f32x16 TileAcc;
+  // Sweep 1.  Running softmax statistics of this lane's row over its half of the units, in log2
+  // units: maximum, and sum of 2^(z log2e - max).  The work on a finished tile, in 27 units that
+  // go between the matrix instructions of the next: the tile's maximum (8); the rescaling of the
+  // running sum; a three-stage pipeline over the values (scaled difference, 2^x, accumulate), one
+  // value entering per unit.
+  float mx = -INFINITY, sm = 0.0f, tm = 0.0f, st3[3];
+  constexpr int kStatUnits = 8 + 1 + 18;
+  auto stats_unit = [&](const TileAcc &acc, auto u_tag) __attribute__((always_inline)) {
+    constexpr int u = decltype(u_tag)::value;
+    if constexpr (u < 8) {
+      if constexpr (u == 0) tm = fmaxf(acc[0], acc[1]);
+      else tm = fmaxf(tm, fmaxf(acc[2 * u], acc[2 * u + 1]));
+      pin_order(tm);
+    } else if constexpr (u == 8) {
+      const float mn = fmaxf(mx, tm * kLog2e);
+      sm *= __builtin_amdgcn_exp2f(mx - mn);  // 2^(-inf) = 0 on the first tile, where sm is 0 too
+      mx = mn;
+      pin_order(sm);
+      pin_order(mx);
+    } else {
+      constexpr int i = u - 9;  // value i enters; i - 1 is exponentiated; i - 2 is added
+      if constexpr (i < 16) {
+        st3[i % 3] = fmaf(acc[i], kLog2e, -mx);
+        pin_order(st3[i % 3]);
+      }
+      if constexpr (i >= 1 && i - 1 < 16) {
+        st3[(i - 1) % 3] = __builtin_amdgcn_exp2f(st3[(i - 1) % 3]);
+        pin_order(st3[(i - 1) % 3]);
+      }
+      if constexpr (i >= 2) {
+        sm += st3[(i - 2) % 3];
+        pin_order(sm);
+      }
+    }
+  };
+  // Sweep 2.  Accumulator register r of this lane is unit li of the tile for row 8 (r / 4) + 4 h +
+  // r % 4 of the wave's 32: log softmax with that row's log Z, floor (or posterior), minus log
+  // prior times scale, one 4-byte store.
+  f32x4 lz4[4];          // log Z of the 16 rows whose values this lane holds
+  float lp_cur = 0.0f;   // this lane's unit's log prior, of the tile finished last (a hidden read)
+  float nlp = 0.0f;      // -scale x log prior of the tile whose values are being written (0 without priors)
+  const float pscale = has_prior ? scale : 1.0f, nscale = -scale;
+  char *const yw = reinterpret_cast<char *>(Y + (size_t)(row0 + w * 32) * ldy);
+  const unsigned ldy4 = (unsigned)ldy * 4u;
+  const int wlast = min(32, nrows - w * 32) - 1;  // the last row of this wave that exists (< 0: none)
+  auto emit_unit = [&](const TileAcc &acc, int n0, auto r_tag, auto checked_tag) __attribute__((always_inline)) {
+    constexpr int r = decltype(r_tag)::value, fr = 8 * (r / 4) + r % 4;
+    constexpr bool kChecked = decltype(checked_tag)::value;
+    float val = acc[r] - lz4[r / 4][r % 4];
+    if constexpr (LOGM) val = fmaxf(val, -46.051701859880914f);  // log(1e-20)
+    else val = floor_1e20(__expf(val));
+    val = fmaf(val, pscale, nlp);
+    // The row's part of the address is wave-uniform and stays in scalar registers; the lane's part
+    // is its unit's 4 bytes plus, in the upper half-wave, the distance to the row 4 further on.
+    // (Left to the compiler, the 16 rows' 64-bit addresses were kept in 32 vector registers.)
+    // A wave with fewer than 32 rows only exists in the job that ends the matrix; the rows it lacks
+    // are copies of the last row, computed from the same operands: their stores go to that row,
+    // with the values its own stores carry (row indices are held at wlast).
+    const int r_lo = min(fr, wlast), r_hi = min(fr + 4, wlast);
+    const char *base = yw + (size_t)n0 * 4 + (size_t)((unsigned)r_lo * ldy4);
+    const unsigned off = __umul24((unsigned)h, (unsigned)(r_hi - r_lo) * ldy4) + (unsigned)li * 4u;
+    if constexpr (kChecked) {
+      if (n0 + li < N) store_f32_at(base, off, val);
+    } else {
+      store_f32_at(base, off, val);
+    }
+  };
+
+  constexpr int kAhead = 2;
+  static_assert(KS % 3 == 1, "the register slots below assume KS = 3 n + 1");
+  f32x4 wf[4][NPL];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) wf[sl][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  const unsigned s_w_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint4 *)s_w +
+                            (unsigned)(h * 32 + li) * 16u;
+  const unsigned s_lp_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)s_lp + (unsigned)lane * 4u;
+  auto load_frag = [&](int seq, auto ks_tag) __attribute__((always_inline)) {  // k-step ks of tile seq
+    constexpr int ks = decltype(ks_tag)::value, slot = ks == KS - 1 ? 3 : ks % 3;
+    const unsigned at = s_w_addr + (unsigned)(seq % kRing) * (unsigned)(kTileU4 * 16);
+    static_for<NPL>([&](auto q_tag) __attribute__((always_inline)) {
+      constexpr int q = decltype(q_tag)::value;
+      lds_hidden_reload_at<(q * 2 * KS + 2 * ks) * 32 * 16>(wf[slot][q], at);
+    });
+  };
+  const bool active = w * 32 < nrows;
+  // One step: the matrix instructions of W tile seq into acc_new (from zero), with the vector work
+  // on the previous tile (acc_old; kind 0: none, 1: sweep-1 statistics, 2: sweep-2 stores of tile
+  // old_n0) between them.  SWEEP2: operands the other way round.  stores_counted: this step and
+  // the kLead - 2 before it each issue all their 16 stores, which are younger than the request
+  // waited for at the end and need not have finished.
+  auto step = [&](int seq, TileAcc &acc_new, const TileAcc &acc_old, auto sweep2_tag, auto kind_tag,
+                  auto checked_tag, int old_n0, bool stores_counted) __attribute__((always_inline)) {
+    constexpr bool kSweep2 = decltype(sweep2_tag)::value;
+    constexpr int kKind = decltype(kind_tag)::value;
+    if (!active) {
+      request(seq + kLead);
+      wait_vector_memory_but<(kLead - 2) * (kMine + 1)>();
+      barrier_only();
+      return;
+    }
+    static_for<KS>([&](auto ks_tag) __attribute__((always_inline)) {
+      constexpr int ks = decltype(ks_tag)::value;
+      if constexpr (ks + kAhead < KS) load_frag(seq, std::integral_constant<int, (ks + kAhead) % KS>());
+      else load_frag(seq + 1, std::integral_constant<int, (ks + kAhead) % KS>());
+      // (past the end of the stream the request wraps around: harmless, and it keeps the count
+      // of outstanding loads the same in every step)
+      if constexpr (ks == 0) request(seq + kLead);
+      constexpr int slot = ks == KS - 1 ? 3 : ks % 3;
+      lds_hidden_wait_but<kAhead * NPL>(wf[slot][0], wf[slot][1]);  // all but the reads of the k-steps ahead
+      static_for<NPROD>([&](auto j_tag) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_tag)::value, mi = ks * NPROD + j;
+        // order within a k-step: the two cross products, then the high parts
+        if constexpr (!kSweep2) {
+          if constexpr (j == 0) mfma_f16_asm_vacc<ks == 0>(acc_new, wf[slot][1], xf[ks][0]);
+          else if constexpr (j == 1) mfma_f16_asm_vacc<false>(acc_new, wf[slot][0], xf[ks][1]);
+          else mfma_f16_asm_vacc<false>(acc_new, wf[slot][0], xf[ks][0]);
+        } else {
+          if constexpr (j == 0) mfma_f16_asm_vacc_swapped<ks == 0>(acc_new, xf[ks][0], wf[slot][1]);
+          else if constexpr (j == 1) mfma_f16_asm_vacc_swapped<false>(acc_new, xf[ks][1], wf[slot][0]);
+          else mfma_f16_asm_vacc_swapped<false>(acc_new, xf[ks][0], wf[slot][0]);
+        }
+        if constexpr (kKind != 0 && mi >= kSkip) {
+          constexpr int NU = kKind == 1 ? kStatUnits : 16;
+          constexpr int u0 = ((mi - kSkip) * NU + NMF - kSkip - 1) / (NMF - kSkip),
+                        u1 = ((mi - kSkip + 1) * NU + NMF - kSkip - 1) / (NMF - kSkip);
+          static_for<u1 - u0>([&](auto d) __attribute__((always_inline)) {
+            if constexpr (kKind == 1) stats_unit(acc_old, std::integral_constant<int, u0 + decltype(d)::value>());
+            else emit_unit(acc_old, old_n0, std::integral_constant<int, u0 + decltype(d)::value>(), checked_tag);
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+    // this tile's log prior for the lane's unit (its values are written in the next step)
+    if constexpr (kSweep2) lds_hidden_read32(lp_cur, s_lp_addr + (unsigned)(seq % kSideRing) * 256u);
+    // every LDS read of this step has delivered before the step ends
+    lds_hidden_wait_but<0>(wf[0][0], wf[0][1]);
+    lds_hidden_wait_but<0>(wf[1][0], wf[1][1]);
+    if constexpr (kSweep2) {
+      lds_hidden_wait32(lp_cur);
+      nlp = has_prior ? lp_cur * nscale : 0.0f;
+    }
+    // tile seq + 2 has landed; every wave has finished reading tile seq
+    if (kKind == 2 && stores_counted) wait_vector_memory_but<(kLead - 2) * (kMine + 1) + (kLead - 1) * 16>();
+    else wait_vector_memory_but<(kLead - 2) * (kMine + 1)>();
+    barrier_only();
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  TileAcc acc_a, acc_b;
+  wait_vector_memory_but<(kLead - 2) * (kMine + 1)>();
+  barrier_only();  // tiles 0 and 1 are in LDS
+  if (active) static_for<kAhead>([&](auto j) __attribute__((always_inline)) { load_frag(0, j); });
+#ifdef AMLIKE_OUTROWS_STAMPS
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // sweep 1
+  step(0, acc_a, acc_b, std::false_type(), K0(), std::false_type(), 0, false);
+  bool in_a = true;  // which set holds the tile finished last
+  for (int t = 1; t < ntile; t += 2) {
+    step(t, acc_b, acc_a, std::false_type(), K1(), std::false_type(), 0, false);
+    in_a = false;
+    if (t + 1 < ntile) {
+      step(t + 1, acc_a, acc_b, std::false_type(), K1(), std::false_type(), 0, false);
+      in_a = true;
+    }
+  }
+  if (active) {
+    mfma_result_gap();
+    static_for<kStatUnits>([&](auto u) __attribute__((always_inline)) {
+      if (in_a) stats_unit(acc_a, u);
+      else stats_unit(acc_b, u);
+    });
+    // the two half-waves hold different units of the same rows
+    const float om = __shfl_xor(mx, 32), os = __shfl_xor(sm, 32);
+    const float mn = fmaxf(mx, om);
+    const float tot = sm * __builtin_amdgcn_exp2f(mx - mn) + os * __builtin_amdgcn_exp2f(om - mn);
+    s_lz[w * 32 + li] = (mn + __log2f(tot)) * kLn2;  // (both half-waves write the same value)
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+      const float4 z = *reinterpret_cast<const float4 *>(s_lz + w * 32 + 8 * part + 4 * h);
+      lz4[part] = (f32x4){z.x, z.y, z.z, z.w};
+    }
+  }
+#ifdef AMLIKE_OUTROWS_STAMPS
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // sweep 2
+  step(ntile, acc_a, acc_b, std::true_type(), K0(), std::false_type(), 0, false);
+  in_a = true;
+  for (int t = 1; t < ntile; t += 2) {
+    step(ntile + t, acc_b, acc_a, std::true_type(), K2(), std::false_type(), (t - 1) << 5, t >= kLead - 1);
+    in_a = false;
+    if (t + 1 < ntile) {
+      step(ntile + t + 1, acc_a, acc_b, std::true_type(), K2(), std::false_type(), t << 5, t + 1 >= kLead - 1);
+      in_a = true;
+    }
+  }
+  if (active) {
+    mfma_result_gap();
+    static_for<16>([&](auto r) __attribute__((always_inline)) {  // the last tile may be narrower than 32 units
+      if (in_a) emit_unit(acc_a, (ntile - 1) << 5, r, std::true_type());
+      else emit_unit(acc_b, (ntile - 1) << 5, r, std::true_type());
+    });
+  }
+  wait_vector_memory_but<0>();  // no load may still be on its way into LDS when the block ends
+#ifdef AMLIKE_OUTROWS_STAMPS
+  if ((int)blockIdx.x == jobs.lead && threadIdx.x == 0) {
+    g_outrows_stamps[0] = c1 - c0;
+    g_outrows_stamps[1] = __builtin_readcyclecounter() - c1;
+    g_outrows_stamps[2] = r1 - r0;
+    g_outrows_stamps[3] = __builtin_amdgcn_s_memrealtime() - r1;
+    g_outrows_stamps[4] = ntile;
+  }
+#endif
+}
+
 // Softmax for rows wider than the register form holds: three passes over the row.
 __global__ void __launch_bounds__(256)
     nnet_softmax_wide_kernel(const float *__restrict__ in, int ld_in, int dim, int rows, int post,
@@ -2024,6 +2366,8 @@ struct Stage {
   // affine followed by a p = 2 p-norm whose group size divides 80: the fused kernel's image
   uint4 *d_wpn = nullptr;   // rows permuted and padded to Npad, bias as column in_dim: [3][Kpn/8][Npad]
   uint4 *d_wpr = nullptr;   // the same in the row order of nnet_pnorm_rows_kernel (fp16x2, groups of 10, Kpn = 208)
+  uint4 *d_wob = nullptr;   // the net's last affine stage before its softmax: fp16x2 planes [2][Kp/8][Nob] with the
+  int Nob = 0;              //   bias as column in_dim and the units padded to whole tiles of 32 (nnet_out_rows_kernel)
   int fuse_gs = 0, Kpn = 0, Npad = 0;
   // 1: operands as fp16x2 (input behind a NormalizeComponent, weights inside the fp16 range);
   // 2: fp16x2 on trial (weights fit, input range unknown): d_wpo_safe / d_wpn_safe hold the
@@ -2050,6 +2394,7 @@ struct amlike_nnet {
   bool gemm_inline_split = false;  // AMLIKE_NNET_GEMM=inline: bf16x3 GEMM that splits X in its k-loop
   int pnorm_rows = 1;  // AMLIKE_NNET_PNORM_ROWS=0: never the row-stationary affine + p-norm kernel (A/B aid)
   int pnorm_xcd_order = 1;  // AMLIKE_NNET_PNORM_XCD=0: launch-order block mapping in the affine + p-norm kernel (A/B aid)
+  int out_rows = 1;  // AMLIKE_NNET_OUT_ROWS=0: never the 8-wave output-layer + softmax kernel (A/B aid)
   int collapse = 1;  // AMLIKE_NNET_COLLAPSE=0: an affine stage right behind another stays a stage of its own (A/B aid)
   float *d_log_priors = nullptr;
   hipStream_t stream = nullptr;
@@ -2087,6 +2432,7 @@ static void FreeStage(Stage &s) {
   (void)hipFree(s.d_wpo);
   (void)hipFree(s.d_wpn);
   (void)hipFree(s.d_wpr);
+  (void)hipFree(s.d_wob);
   (void)hipFree(s.d_wpo_safe);
   (void)hipFree(s.d_wpn_safe);
   (void)hipFree(s.d_bias);
@@ -2229,6 +2575,75 @@ static int LaunchPnormRows(const Stage &s, const uint4 *xp, size_t xplane, float
                 (double)(hs[8 * k] + hs[8 * k + 1] + hs[8 * k + 2]) / hs[8 * k + 3], (double)hs[8 * k] / hs[8 * k + 3],
                 (double)hs[8 * k + 1] / hs[8 * k + 3], (double)hs[8 * k + 2] / hs[8 * k + 3], (double)hs[8 * k + 4],
                 hs[8 * k + 5] * 0.01, hs[8 * k + 4] / (hs[8 * k + 5] * 10.0), hs[8 * k + 3]);
+  }
+#endif
+  return AMLIKE_OK;
+}
+
+// The operand image of nnet_out_rows_kernel: fp16x2 planes [2][Kp/8][Npad] in k-octet-major order,
+// the bias as column K, the units padded to whole tiles of 32 by units of weight 0 and bias
+// -60000 (exact in fp16: their exponential is 0 whatever the row's maximum).
+static std::vector<uint16_t> BuildOutRowsWeights(const std::vector<float> &w, int ldw,
+                                                 const std::vector<float> &bias, int N, int K, int Kp,
+                                                 int *Npad) {
+  *Npad = RoundUp(N, 32);
+  const size_t np = *Npad;
+  std::vector<uint16_t> out(2 * np * Kp, 0);
+  for (size_t u = 0; u < np; ++u)
+    for (int k = 0; k <= K; ++k) {
+      const float val = u < (size_t)N ? (k < K ? w[u * ldw + k] : bias[u]) : (k < K ? 0.0f : -60000.0f);
+      uint16_t parts[3];
+      SplitParts(val, 1, parts);
+      for (int q = 0; q < 2; ++q) out[q * np * Kp + (((size_t)(k / 8) * np + u) * 8) + (k % 8)] = parts[q];
+    }
+  return out;
+}
+
+static int LaunchOutRows(const Stage &s, const uint4 *xp, size_t xplane, const float *log_priors, float *y,
+                         int ldy, int rows, int post, float scale, hipStream_t st) {
+  if ((post & kPostPrior) && !log_priors) {
+    SetError("amlike_nnet_compute: log-likelihoods asked for, but the net has no priors");
+    return AMLIKE_EINVAL;
+  }
+  // Jobs as for nnet_out_softmax_kernel: full rounds of 256-row jobs, the rest in equal shares of a
+  // multiple of 32 rows; half of the CUs start with a short job (when the short jobs are short),
+  // so that the two halves of the chip are in different sweeps from then on.
+  int cus = std::max(1, NumComputeUnits());
+  if (const char *e = getenv("AMLIKE_NNET_OUT_CUS")) cus = std::max(1, atoi(e));  // testing aid: job shapes of a smaller chip
+  OutJobs jobs;
+  jobs.nbig = (rows / 256 / cus) * cus;
+  const int rest = rows - jobs.nbig * 256;
+  int nsmall = 0;
+  jobs.small = 256;
+  if (rest > 0) {
+    jobs.small = std::min(256, RoundUp((rest + cus - 1) / cus, 32));
+    nsmall = (rest + jobs.small - 1) / jobs.small;
+  }
+  jobs.lead = jobs.nbig > 0 && jobs.small <= 128 ? std::min(nsmall, cus / 2) : 0;
+  if (getenv("AMLIKE_NNET_OUT_NO_STAGGER")) jobs.lead = 0;  // tuning aid
+  const int grid = jobs.nbig + nsmall;
+  constexpr int KS = 13;
+  const size_t wplane = (size_t)s.Nob * (s.Kp / 8);
+  const size_t smem = (size_t)OutRowsRing(KS) * 2 * 2 * KS * 32 * sizeof(uint4) + 8 * 256 + 8 * 128;
+#define AMLIKE_OUTROWS_LAUNCH(LOGM)                                                                       \
+  do {                                                                                                    \
+    AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nnet_out_rows_kernel<KS, LOGM>),        \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));               \
+    hipLaunchKernelGGL((nnet_out_rows_kernel<KS, LOGM>), dim3(grid), dim3(512), smem, st, xp, xplane,     \
+                       s.d_wob, wplane, s.Nob, (post & kPostPrior) ? log_priors : nullptr, y, ldy, rows,  \
+                       s.out_dim, post, scale, jobs);                                                     \
+  } while (0)
+  if (post & kPostFloorLog) AMLIKE_OUTROWS_LAUNCH(true);
+  else AMLIKE_OUTROWS_LAUNCH(false);
+#undef AMLIKE_OUTROWS_LAUNCH
+  AMLIKE_HIP(hipGetLastError());
+#ifdef AMLIKE_OUTROWS_STAMPS
+  {
+    AMLIKE_HIP(hipStreamSynchronize(st));
+    unsigned long long hs[8];
+    if (hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_outrows_stamps), sizeof(hs)) == hipSuccess && hs[4])
+      fprintf(stderr, "out rows job 0: sweep 1 %.0f ticks/tile (%.3f us), sweep 2 %.0f ticks/tile (%.3f us), %llu tiles\n",
+              (double)hs[0] / hs[4], hs[2] * 0.01 / hs[4], (double)hs[1] / hs[4], hs[3] * 0.01 / hs[4], hs[4]);
   }
 #endif
   return AMLIKE_OK;
@@ -2495,7 +2910,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         if (rc != AMLIKE_OK) return rc;
         unsigned short *pbase = static_cast<unsigned short *>(n->ws_planes.ptr);
         int *flag = n->d_flags + si + 1;
-        const int one_col = cons_fused ? cons->in_dim : -1;
+        const int one_col = (cons_fused || cons->d_wob) ? cons->in_dim : -1;
         const int sblocks = (int)((total + 63) / 64);
         const size_t ssmem = (size_t)kSpliceStageRows * (s.in_dim | 1) * sizeof(float);
         const int lp = padded ? 0 : pad_l, nspl = s.left + s.right + 1, sdim = s.in_dim - s.const_dim;
@@ -2612,14 +3027,16 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         rc = n->ws_planes.Reserve(3 * cstride * sizeof(unsigned short));  // what the consumer asks for
         if (rc != AMLIKE_OK) return rc;
         Planes cp{static_cast<unsigned short *>(n->ws_planes.ptr), cstride, ckp};
+        // the 1.0 the consumer's bias column multiplies (fused affine + p-norm, 8-wave output layer)
+        const int cons_one = (cons_fused || cons->d_wob) ? cons->in_dim : -1;
         const int rb = G <= 240 ? 64 : 32;
         const size_t nsmem = ((size_t)rb * (G | 1) + 256) * sizeof(float);
         if (rb == 64)
           hipLaunchKernelGGL(nnet_normalize_planes_kernel<64>, dim3((unsigned)((cur_rows + 63) / 64)), dim3(256),
-                             nsmem, st, pdst, pld, G, (int)cur_rows, cp, cons_fused ? cons->in_dim : -1);
+                             nsmem, st, pdst, pld, G, (int)cur_rows, cp, cons_one);
         else
           hipLaunchKernelGGL(nnet_normalize_planes_kernel<32>, dim3((unsigned)((cur_rows + 31) / 32)), dim3(256),
-                             nsmem, st, pdst, pld, G, (int)cur_rows, cp, cons_fused ? cons->in_dim : -1);
+                             nsmem, st, pdst, pld, G, (int)cur_rows, cp, cons_one);
         AMLIKE_HIP(hipGetLastError());
         planes_ready = 1;
         fin = nullptr;  // no fp32 copy exists
@@ -2664,15 +3081,20 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
         if (s.f16)
           hipLaunchKernelGGL(nnet_split_planes_kernel<1>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld, s.in_dim,
-                             (int)cur_rows, xp, -1, nullptr, 0);
+                             (int)cur_rows, xp, s.d_wob ? s.in_dim : -1, nullptr, 0);
         else
           hipLaunchKernelGGL(nnet_split_planes_kernel<0>, dim3(sblocks), dim3(256), 0, st, cur, cur_ld, s.in_dim,
                              (int)cur_rows, xp, -1, nullptr, 0);
         AMLIKE_HIP(hipGetLastError());
       }
       planes_ready = 0;
-      rc = LaunchOutSoftmax(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, n->d_log_priors, d_out, ldo,
-                            (int)cur_rows, post, prob_scale, st);
+      // (the planes carry 1.0 in column in_dim whenever d_wob exists: the 8-wave kernel's bias column)
+      if (s.d_wob && n->out_rows && cur_rows >= 64 && ldo < (1 << 20))  // (24-bit row-offset arithmetic)
+        rc = LaunchOutRows(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, n->d_log_priors, d_out, ldo,
+                           (int)cur_rows, post, prob_scale, st);
+      else
+        rc = LaunchOutSoftmax(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, n->d_log_priors, d_out, ldo,
+                              (int)cur_rows, post, prob_scale, st);
       if (rc != AMLIKE_OK) return rc;
       cur = d_out;
       cur_ld = ldo;
@@ -2830,6 +3252,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
   if (const char *e = getenv("AMLIKE_NNET_PNORM_XCD")) n->pnorm_xcd_order = e[0] != '0';
   if (const char *e = getenv("AMLIKE_NNET_PNORM_ROWS")) n->pnorm_rows = e[0] != '0';
   if (const char *e = getenv("AMLIKE_NNET_COLLAPSE")) n->collapse = e[0] != '0';
+  if (const char *e = getenv("AMLIKE_NNET_OUT_ROWS")) n->out_rows = e[0] != '0';
   n->input_dim = comps[0].input_dim;
   int dim = comps[0].input_dim;
   int rc = AMLIKE_OK;
@@ -3122,6 +3545,21 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
     dim = c.output_dim;
   }
   n->output_dim = dim;
+  // the net's last affine stage, behind a NormalizeComponent and in front of the closing softmax,
+  // with room for the bias among its padded k columns: the image of nnet_out_rows_kernel
+  if (rc == AMLIKE_OK && n->stages.size() >= 2 && n->stages.back().kind == AMLIKE_SOFTMAX) {
+    Stage &a = n->stages[n->stages.size() - 2];
+    if (a.kind == AMLIKE_AFFINE && !a.fuse_gs && a.f16 == 1 && a.Kp == 208 && a.in_dim < a.Kp && !a.h_w.empty() &&
+        n->out_rows) {
+      std::vector<uint16_t> img = BuildOutRowsWeights(a.h_w, a.Kp, a.h_b, a.out_dim, a.in_dim, a.Kp, &a.Nob);
+      hipError_t e = hipMalloc(&a.d_wob, img.size() * sizeof(uint16_t));
+      if (e == hipSuccess) e = hipMemcpy(a.d_wob, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        SetError("amlike_nnet_create: %s", hipGetErrorString(e));
+        rc = e == hipErrorOutOfMemory ? AMLIKE_EOOM : AMLIKE_EHIP;
+      }
+    }
+  }
   for (Stage &st : n->stages) {
     std::vector<float>().swap(st.h_w);
     std::vector<float>().swap(st.h_b);

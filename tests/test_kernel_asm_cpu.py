@@ -1,12 +1,12 @@
 """Static checks on the device code of libamlike.so (no GPU needed).
 
-nnet_pnorm_rows_kernel issues its matrix instructions and its LDS fragment reads as inline
-assembly, which the compiler does not understand: it knows neither that a matrix instruction
+nnet_pnorm_rows_kernel and nnet_out_rows_kernel issue their matrix instructions and their LDS
+fragment reads as inline assembly, which the compiler does not understand: it knows neither that a matrix instruction
 delivers its result tens of cycles after issue and fetches its operands late, nor that a register
 filled by such an LDS read is only valid after the wave's counted wait.  Any register-to-register
 copy the compiler inserts around them (it did, in an earlier form of the output-layer kernel: the
 accumulators were copied right behind the matrix instruction that wrote them) silently reads stale
-data.  The kernel is written so that no such copy is needed; this test holds the built code to it."""
+data.  The kernels are written so that no such copy is needed; this test holds the built code to it."""
 import os
 import re
 import shutil
@@ -46,24 +46,27 @@ def regs(operand):
     return {int(m.group(1))} if m else set()
 
 
-def test_nothing_touches_a_matrix_instructions_registers_right_behind_it_in_the_rows_kernel():
+@pytest.mark.parametrize("kernel,steps", [("nnet_pnorm_rows_kernel", 3), ("nnet_out_rows_kernel", 6)])
+def test_nothing_touches_a_matrix_instructions_registers_right_behind_it(kernel, steps):
     """For every matrix instruction and the six instructions behind it: no vector instruction reads
-    or writes its result registers, and none writes its first operand's registers (an LDS read may
-    name them as its destination: its data arrives long after)."""
-    code = disassemble_kernel("nnet_pnorm_rows_kernel")
-    assert sum(l.startswith("v_mfma") for l in code) >= 39 * 3  # three instances of the step
+    or writes its result registers, and none writes its operands' registers (an LDS read may name
+    them as its destination: its data arrives long after).  `steps`: instances of the 39-instruction
+    step the kernel is known to hold at least."""
+    code = disassemble_kernel(kernel)
+    assert sum(l.startswith("v_mfma") for l in code) >= 39 * steps
     assert not any(l.startswith("v_accvgpr") for l in code)
+    assert not any(l.startswith("scratch_") for l in code)  # no spills
     bad = []
     for i, l in enumerate(code):
         if not l.startswith("v_mfma"):
             continue
         ops = [o.strip() for o in l.split(None, 1)[1].split(",")]
-        dst, src_a = regs(ops[0]), regs(ops[1])
+        dst, src = regs(ops[0]), regs(ops[1]) | regs(ops[2])
         for later in code[i + 1:i + 7]:
             if later.startswith("v_mfma") or not later.startswith("v_"):
                 continue
             lops = [o.strip() for o in later.split(None, 1)[1].split(",")]
             written, read = regs(lops[0]), set().union(*[regs(o) for o in lops[1:]]) if len(lops) > 1 else set()
-            if (written | read) & dst or written & src_a:
+            if (written | read) & dst or written & src:
                 bad.append((l, later))
     assert not bad, "vector instructions too close behind a matrix instruction: %s" % bad[:3]
