@@ -1635,7 +1635,7 @@ template <int KS>
 __global__ void __launch_bounds__(512, 2)
     nnet_pnorm_rows_kernel(const uint4 *__restrict__ Xp, size_t xplane, const uint4 *__restrict__ Wp,
                            size_t wplane, int Npad, float *__restrict__ Y, int ldy, int M, int G,
-                           RowJobs jobs) {
+                           RowJobs jobs, Planes nout, int one_col) {
   constexpr int NPL = 2, NPROD = 3, NW = 8;
   constexpr int kTileU4 = NPL * 2 * KS * 32;  // uint4 per staged W tile: [plane][octet][32 units]
   constexpr int kRing = PnormRowsRing(KS), kLead = kRing - 1;  // tile seq + kLead is requested in step seq
@@ -1717,8 +1717,16 @@ __global__ void __launch_bounds__(512, 2)
     pin_order(ss[r & 7]);
   };
   // the groups of super-tile `sup` are complete: this lane's 8 (half h) of its row
+  float rowsq = 0.0f;  // the sum of the squares of this lane's p-norm outputs of its row (groups < G)
   auto finish_groups = [&](int sup) __attribute__((always_inline)) {
     const int g0 = 16 * sup + 8 * h;
+    if (g0 + 8 <= G) {
+      rowsq += ((ss[0] + ss[1]) + (ss[2] + ss[3])) + ((ss[4] + ss[5]) + (ss[6] + ss[7]));
+    } else {
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+        if (g0 + g < G) rowsq += ss[g];
+    }
     float4 lo = make_float4(sqrtf(ss[0]), sqrtf(ss[1]), sqrtf(ss[2]), sqrtf(ss[3]));
     float4 hi = make_float4(sqrtf(ss[4]), sqrtf(ss[5]), sqrtf(ss[6]), sqrtf(ss[7]));
     if (rl < nrows) {
@@ -1870,6 +1878,56 @@ __global__ void __launch_bounds__(512, 2)
   });
   finish_groups(ntile / 5 - 1);
   wait_vector_memory_but<0>();  // no load may still be on its way into LDS when the block ends
+  if (nout.p) {
+    // The NormalizeComponent behind the p-norm, and the next affine stage's fp16x2 operand planes
+    // (nnet2/nnet-component.cc:578-592; the layout nnet_normalize_planes_kernel writes): the wave
+    // reads its 32 rows back (they are in L2), scales each by 1 / sqrt(max(sum of squares / G,
+    // 2^-66)) and writes plane q, octet o, row r as 16 bytes; half-wave h takes the octets o = h
+    // (mod 2).  (The stores of Y above have finished: the wait counted them.)
+    const float tot = rowsq + __shfl_xor(rowsq, 32);
+    const float f = 1.0f / sqrtf(fmaxf(tot / G, 1.3552527156068805e-20f));
+    if (rl < nrows) {
+      const float *x = Y + (size_t)(row0 + rl) * ldy;
+      uint4 *o = reinterpret_cast<uint4 *>(nout.p);
+      const size_t pstride = nout.stride >> 3;
+      // four octets at a time: their eight loads are in flight together (a lane reads its own
+      // row, so every load instruction touches 32 lines of L2 and its latency is what counts)
+      const int kp8 = nout.Kp >> 3;
+      for (int oct0 = h; oct0 < kp8; oct0 += 8) {
+        float4 a[4], bq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c0 = (oct0 + 2 * u) * 8;
+          if (c0 + 8 <= G) {
+            a[u] = *reinterpret_cast<const float4 *>(x + c0);
+            bq[u] = *reinterpret_cast<const float4 *>(x + c0 + 4);
+          } else {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = c0 + j < G ? x[c0 + j] : 0.0f;
+            a[u] = make_float4(t[0], t[1], t[2], t[3]);
+            bq[u] = make_float4(t[4], t[5], t[6], t[7]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int oct = oct0 + 2 * u, c0 = oct * 8;
+          if (oct >= kp8) break;
+          float t[8] = {a[u].x * f, a[u].y * f, a[u].z * f, a[u].w * f, bq[u].x * f, bq[u].y * f, bq[u].z * f, bq[u].w * f};
+          if (one_col >= c0 && one_col < c0 + 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (c0 + j == one_col) t[j] = 1.0f;
+          }
+          uint4 s0, s1;
+          split_f16x2_8(make_float4(t[0], t[1], t[2], t[3]), make_float4(t[4], t[5], t[6], t[7]), s0, s1);
+          const size_t i = (size_t)oct * M + (row0 + rl);
+          o[i] = s0;
+          o[pstride + i] = s1;
+        }
+      }
+    }
+  }
 #ifdef AMLIKE_ROWS_STAMPS
   if (blockIdx.x == 0 && lane == 0 && (w == 0 || w == 4)) {
     unsigned long long *o = g_rows_stamps + (w ? 8 : 0);
@@ -2394,6 +2452,7 @@ struct amlike_nnet {
   bool gemm_inline_split = false;  // AMLIKE_NNET_GEMM=inline: bf16x3 GEMM that splits X in its k-loop
   int pnorm_rows = 1;  // AMLIKE_NNET_PNORM_ROWS=0: never the row-stationary affine + p-norm kernel (A/B aid)
   int pnorm_xcd_order = 1;  // AMLIKE_NNET_PNORM_XCD=0: launch-order block mapping in the affine + p-norm kernel (A/B aid)
+  int rows_norm = 1;  // AMLIKE_NNET_ROWS_NORM=0: the normalisation behind the row-stationary kernel stays a kernel of its own (A/B aid)
   int out_rows = 1;  // AMLIKE_NNET_OUT_ROWS=0: never the 8-wave output-layer + softmax kernel (A/B aid)
   int collapse = 1;  // AMLIKE_NNET_COLLAPSE=0: an affine stage right behind another stays a stage of its own (A/B aid)
   float *d_log_priors = nullptr;
@@ -2402,7 +2461,7 @@ struct amlike_nnet {
   AsyncSlot slots[kAsyncSlots];
   std::vector<UttMap> slot_utts[kAsyncSlots];  // the row maps a submission's upload reads
   int32_t next_ticket = 0;
-  DeviceBuffer ws_a, ws_b, ws_in, ws_out, ws_utts, ws_planes;
+  DeviceBuffer ws_a, ws_b, ws_in, ws_out, ws_utts, ws_planes, ws_planes_b;
   int *d_flags = nullptr;  // one range flag per stage (fp16x2 on trial)
   std::vector<UttMap> h_utts;
   PinnedUploadRing uploads;  // h_utts on its way to ws_utts
@@ -2449,6 +2508,7 @@ static void FreeNnet(amlike_nnet *n) {
   n->ws_out.Free();
   n->ws_utts.Free();
   n->ws_planes.Free();
+  n->ws_planes_b.Free();
   for (AsyncSlot &s : n->slots) s.Release();
   if (n->copy_stream) (void)hipStreamDestroy(n->copy_stream);
   if (n->stream) (void)hipStreamDestroy(n->stream);
@@ -2542,7 +2602,7 @@ static std::vector<uint16_t> BuildPnormRowsWeights(const std::vector<float> &w, 
 }
 
 static int LaunchPnormRows(const Stage &s, const uint4 *xp, size_t xplane, float *y, int ldy, int rows, int G,
-                           hipStream_t st) {
+                           hipStream_t st, Planes nout = Planes{nullptr, 0, 0}, int one_col = -1) {
   // Jobs: as many full rounds of 256-row jobs as the CUs take evenly, then the rest in equal
   // shares (multiples of 32 rows) so that the last round is short everywhere.
   const int cus = std::max(1, NumComputeUnits());
@@ -2562,7 +2622,7 @@ static int LaunchPnormRows(const Stage &s, const uint4 *xp, size_t xplane, float
   AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nnet_pnorm_rows_kernel<13>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL((nnet_pnorm_rows_kernel<13>), dim3(grid), dim3(512), smem, st, xp, xplane, s.d_wpr, wplane,
-                     s.Npad, y, ldy, rows, G, jobs);
+                     s.Npad, y, ldy, rows, G, jobs, nout, one_col);
   AMLIKE_HIP(hipGetLastError());
 #ifdef AMLIKE_ROWS_STAMPS
   {
@@ -2883,7 +2943,10 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
     cur_rows = gather_rows[gi++];
     which ^= 1;
   }
-  // Set when the previous stage has already written this stage's operand planes into ws_planes
+  // The operand planes in use: a stage that writes its consumer's planes while other blocks of its
+  // own kernel still read its input planes writes them into the other buffer, which then takes over.
+  DeviceBuffer *wsp = &n->ws_planes;
+  // Set when the previous stage has already written this stage's operand planes into *wsp
   // (nnet_normalize_planes_kernel): the split pass is then skipped.
   int planes_ready = 0;
   for (size_t si = 0; si < ns; ++si) {
@@ -2906,9 +2969,9 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         const int ckp = cons_fused ? cons->Kpn : cons->Kp;
         const int64_t total = gather_rows[gi];
         const size_t cstride = (size_t)total * ckp;
-        rc = n->ws_planes.Reserve((cons->f16 == 2 ? 5 : 3) * cstride * sizeof(unsigned short));
+        rc = wsp->Reserve((cons->f16 == 2 ? 5 : 3) * cstride * sizeof(unsigned short));
         if (rc != AMLIKE_OK) return rc;
-        unsigned short *pbase = static_cast<unsigned short *>(n->ws_planes.ptr);
+        unsigned short *pbase = static_cast<unsigned short *>(wsp->ptr);
         int *flag = n->d_flags + si + 1;
         const int one_col = (cons_fused || cons->d_wob) ? cons->in_dim : -1;
         const int sblocks = (int)((total + 63) / 64);
@@ -2957,9 +3020,9 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       const bool pn_last = (si + 2 == ns);
       const size_t pstride = (size_t)cur_rows * s.Kpn;
       // fp16x2 on trial keeps both plane images: [2 planes fp16][3 planes bf16]
-      rc = n->ws_planes.Reserve((s.f16 == 2 ? 5 : 3) * pstride * sizeof(unsigned short));
+      rc = wsp->Reserve((s.f16 == 2 ? 5 : 3) * pstride * sizeof(unsigned short));
       if (rc != AMLIKE_OK) return rc;
-      unsigned short *pbase = static_cast<unsigned short *>(n->ws_planes.ptr);
+      unsigned short *pbase = static_cast<unsigned short *>(wsp->ptr);
       int *flag = n->d_flags + si;
       const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
       auto split = [&](int prec, unsigned short *dstp, int gmode) {
@@ -3000,9 +3063,32 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         AMLIKE_HIP(hipGetLastError());
         fused(0, pbase + 2 * pstride, s.d_wpn_safe, 2);
       } else if (s.d_wpr && cur_rows >= 64) {
-        // rows stationary: X read once per job, the units streamed (nnet_pnorm_rows_kernel)
+        // rows stationary: X read once per job, the units streamed (nnet_pnorm_rows_kernel); the
+        // kernel also normalises its rows and writes the next affine stage's planes when that
+        // stage reads fp16x2 planes of this width
         split(s.f16, pbase, 0);
         AMLIKE_HIP(hipGetLastError());
+        const Stage *nx = (norm && si + 2 < ns) ? &n->stages[si + 2] : nullptr;
+        if (nx && nx->kind == AMLIKE_AFFINE && nx->f16 == 1 && nx->in_dim == G && G <= 480 && n->rows_norm &&
+            !n->gemm_f32 && !n->gemm_inline_split && !getenv("AMLIKE_NNET_NO_DIRECT_PLANES")) {
+          const bool nx_fused = nx->fuse_gs && si + 3 < ns;
+          const int ckp = nx_fused ? nx->Kpn : nx->Kp;
+          const size_t cstride = (size_t)cur_rows * ckp;
+          DeviceBuffer *other = wsp == &n->ws_planes ? &n->ws_planes_b : &n->ws_planes;
+          rc = other->Reserve(3 * cstride * sizeof(unsigned short));
+          if (rc != AMLIKE_OK) return rc;
+          rc = LaunchPnormRows(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, pdst, pld, (int)cur_rows, G, st,
+                               Planes{static_cast<unsigned short *>(other->ptr), cstride, ckp},
+                               (nx_fused || nx->d_wob) ? nx->in_dim : -1);
+          if (rc != AMLIKE_OK) return rc;
+          wsp = other;
+          planes_ready = 1;
+          cur = nullptr;  // no fp32 copy of the normalised rows exists
+          cur_ld = RoundUp(G, 16);
+          which ^= 1;
+          ++si;  // the p-norm stage is done
+          continue;
+        }
         rc = LaunchPnormRows(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, pdst, pld, (int)cur_rows, G, st);
         if (rc != AMLIKE_OK) return rc;
       } else {
@@ -3024,9 +3110,9 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         const bool cons_fused = cons->fuse_gs && si + 3 < ns;
         const int ckp = cons_fused ? cons->Kpn : cons->Kp;
         const size_t cstride = (size_t)cur_rows * ckp;
-        rc = n->ws_planes.Reserve(3 * cstride * sizeof(unsigned short));  // what the consumer asks for
+        rc = wsp->Reserve(3 * cstride * sizeof(unsigned short));  // what the consumer asks for
         if (rc != AMLIKE_OK) return rc;
-        Planes cp{static_cast<unsigned short *>(n->ws_planes.ptr), cstride, ckp};
+        Planes cp{static_cast<unsigned short *>(wsp->ptr), cstride, ckp};
         // the 1.0 the consumer's bias column multiplies (fused affine + p-norm, 8-wave output layer)
         const int cons_one = (cons_fused || cons->d_wob) ? cons->in_dim : -1;
         const int rb = G <= 240 ? 64 : 32;
@@ -3069,9 +3155,9 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       const Stage &sm = n->stages[si + 1];
       (void)sm;
       const size_t pstride = (size_t)cur_rows * s.Kp;
-      rc = n->ws_planes.Reserve(3 * pstride * sizeof(unsigned short));
+      rc = wsp->Reserve(3 * pstride * sizeof(unsigned short));
       if (rc != AMLIKE_OK) return rc;
-      unsigned short *pbase = static_cast<unsigned short *>(n->ws_planes.ptr);
+      unsigned short *pbase = static_cast<unsigned short *>(wsp->ptr);
       if (!planes_ready) {
         if (cur_ld < s.Kp || (cur_ld & 3) || (reinterpret_cast<uintptr_t>(cur) & 15)) {
           SetError("amlike_nnet_compute: internal layout error before the output layer");
@@ -3116,9 +3202,9 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         // the input as bf16x3 planes (one cheap pass), then the conversion-free GEMM
         const bool big_out = (size_t)cur_rows * s.out_dim * sizeof(float) > kStreamingBytes;
         const size_t pstride = (size_t)cur_rows * s.Kp;
-        rc = n->ws_planes.Reserve((s.f16 == 2 ? 5 : 3) * pstride * sizeof(unsigned short));
+        rc = wsp->Reserve((s.f16 == 2 ? 5 : 3) * pstride * sizeof(unsigned short));
         if (rc != AMLIKE_OK) return rc;
-        unsigned short *pbase = static_cast<unsigned short *>(n->ws_planes.ptr);
+        unsigned short *pbase = static_cast<unsigned short *>(wsp->ptr);
         int *flag = n->d_flags + si;
         const int sblocks = (int)std::min<size_t>((pstride / 8 + 255) / 256, 16384);
         auto split_gemm = [&](int prec, unsigned short *xpl, const uint4 *wpo, int gmode) {
@@ -3253,6 +3339,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
   if (const char *e = getenv("AMLIKE_NNET_PNORM_ROWS")) n->pnorm_rows = e[0] != '0';
   if (const char *e = getenv("AMLIKE_NNET_COLLAPSE")) n->collapse = e[0] != '0';
   if (const char *e = getenv("AMLIKE_NNET_OUT_ROWS")) n->out_rows = e[0] != '0';
+  if (const char *e = getenv("AMLIKE_NNET_ROWS_NORM")) n->rows_norm = e[0] != '0';
   n->input_dim = comps[0].input_dim;
   int dim = comps[0].input_dim;
   int rc = AMLIKE_OK;

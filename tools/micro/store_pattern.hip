@@ -57,6 +57,42 @@ __global__ void __launch_bounds__(256) row_store_seg(float *y, int ldy, int rows
   }
 }
 
+// The pattern of a unit-stationary second sweep: a block's 8 waves own 8 neighbouring tiles of 32
+// units (1 KiB of every row) and walk the rows of a row range 32 at a time; a step of a wave is 16
+// 4-byte stores per lane, each instruction writing the 128 bytes of two rows.  The blocks of one
+// XCD (block id modulo 8) take the strips of one row range after the other (XCD_AWARE), so that at
+// any time the XCD's CUs write neighbouring strips of the same rows through their common L2; or
+// the strips of a range are dealt over all XCDs (XCD_AWARE = 0).
+template <int SLEEP, int XCD_AWARE>
+__global__ void __launch_bounds__(512) strip_store(float *y, int ldy, int rows, int ntile, int ranges) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
+  const int strips = (ntile + 7) / 8;
+  int range, strip;
+  if (XCD_AWARE) {
+    const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+    range = xcd * (ranges / 8) + j / strips;
+    strip = j % strips;
+    if (j / strips >= ranges / 8) return;
+  } else {
+    range = blockIdx.x / strips;
+    strip = blockIdx.x % strips;
+    if (range >= ranges) return;
+  }
+  const int tile = strip * 8 + w;
+  if (tile >= ntile) return;
+  const int per = rows / ranges, r0 = range * per;
+  const unsigned ldy4 = ldy * 4u, off = 4u * h * ldy4 + 4u * li;
+  for (int r = r0; r + 32 <= r0 + per; r += 32) {
+    char *base = reinterpret_cast<char *>(y + (size_t)r * ldy + tile * 32);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int fr = 8 * (k / 4) + k % 4;
+      *reinterpret_cast<float *>(base + (size_t)fr * ldy4 + off) = (float)k;
+    }
+    if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+  }
+}
+
 int main() {
   const int ldy = 8600, rows = 256 * 256 * 2, ntile = 268;  // 268 * 32 = 8576 <= 8600
   float *y;
@@ -109,6 +145,27 @@ int main() {
   run_seg("rows, segments of 256 bytes (16 lanes)", row_store_seg<16>, 16);
   run_seg("rows, segments of 512 bytes (32 lanes)", row_store_seg<32>, 32);
   run_seg("rows, segments of 1024 bytes (64 lanes)", row_store_seg<64>, 64);
+  auto run_strip = [&](const char *what, auto kernel, int ranges) {
+    const int strips = (ntile + 7) / 8;
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+      CHECK(hipEventRecord(e0));
+      hipLaunchKernelGGL(kernel, dim3(strips * ranges), dim3(512), 0, 0, y, ldy, rows, ntile, ranges);
+      CHECK(hipEventRecord(e1));
+      CHECK(hipEventSynchronize(e1));
+      float ms;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      best = ms < best ? ms : best;
+    }
+    const double wr = (double)(rows / ranges / 32 * 32) * ranges * ntile * 128.0;
+    printf("%-64s %7.3f ms  %5.2f TB/s\n", what, best, wr / best / 1e9);
+  };
+  run_strip("strips of 8 tiles, 64 row ranges, one range per XCD at a time", strip_store<0, 1>, 64);
+  run_strip("strips of 8 tiles, 64 row ranges, strips dealt over the XCDs", strip_store<0, 0>, 64);
+  run_strip("strips, one range per XCD at a time, s_sleep 16 per step", strip_store<16, 1>, 64);
+  run_strip("strips, one range per XCD at a time, s_sleep 24 per step", strip_store<24, 1>, 64);
+  run_strip("strips dealt over the XCDs, s_sleep 24 per step", strip_store<24, 0>, 64);
+  run_strip("strips, 16 row ranges, one range per XCD at a time", strip_store<0, 1>, 16);
   CHECK(hipFree(y));
   return 0;
 }
