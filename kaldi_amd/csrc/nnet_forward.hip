@@ -1966,6 +1966,15 @@ __device__ __forceinline__ void mfma_f16_asm_vacc_swapped(f32x16 &acc, const bf1
   else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
 #endif
 }
+// Per lane: `b` where the lane's bit of the wave-uniform mask m is set, else `a`.
+template <class T>
+__device__ __forceinline__ T select_lanes(T a, T b, unsigned long long m) {
+  T d = a;
+#if __HIP_DEVICE_COMPILE__
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(m));
+#endif
+  return d;
+}
 // Stores `val` at base + off: base wave-uniform (scalar registers), off a byte offset per lane.
 __device__ __forceinline__ void store_f32_at(const char *base, unsigned off, float val) {
 #if __HIP_DEVICE_COMPILE__
@@ -1982,6 +1991,9 @@ __device__ __forceinline__ void lds_hidden_wait32(float &v) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
 #endif
 }
+#ifndef AMLIKE_OUTROWS_ABL
+#define AMLIKE_OUTROWS_ABL 0
+#endif
 #ifdef AMLIKE_OUTROWS_STAMPS  // diagnostic build: clock ticks of the two sweeps of the first 256-row job
 __device__ unsigned long long g_outrows_stamps[8];
 #endif
@@ -2047,10 +2059,13 @@ __global__ void __launch_bounds__(512, 2)
 
   constexpr int NMF = KS * NPROD;  // matrix instructions per W tile
   constexpr int kSkip = 3;         // matrix instructions of a step issued before the previous tile's values are read
-  const int rl = w * 32 + li;      // this lane's row within the job (sweep 1)
+  // A wave's 32 rows.  The job that ends the matrix may hold a wave with fewer: that wave takes the
+  // last 32 rows of the matrix instead, recomputing some of its neighbour's (the same operands
+  // through the same instructions: the same bits, written twice).  Every active wave is then whole.
+  const int wbase = min(row0 + w * 32, M - 32);
   bf16x8_t xf[KS][NPL];
   {
-    const size_t r = (size_t)min(row0 + rl, M - 1);
+    const size_t r = (size_t)(wbase + li);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -2100,35 +2115,58 @@ __global__ void __launch_bounds__(512, 2)
   };
   // Sweep 2.  Accumulator register r of this lane is unit li of the tile for row 8 (r / 4) + 4 h +
   // r % 4 of the wave's 32: log softmax with that row's log Z, floor (or posterior), minus log
-  // prior times scale, one 4-byte store.
+  // prior times scale.  Rows are ldy floats apart and ldy need not be a multiple of 32: a tile's 32
+  // units of a row then straddle two 128-byte lines, and a partly written line costs the memory
+  // about as much as two whole ones (measured: 3 TB/s against 5.5 TB/s for the same stores on
+  // whole lines).  So a store instruction writes whole lines: the lanes at or past the row's line
+  // boundary `b` carry the PREVIOUS tile's value (kept in `prev`), the lanes before it this
+  // tile's, 128 bytes further on -- together the line that begins in the previous tile.  With ldy a
+  // multiple of 8 the boundary depends on r % 4 only: four lane masks in scalar registers.  The
+  // row's first and last partial lines are written by themselves (first_emit, the epilogue).
   f32x4 lz4[4];          // log Z of the 16 rows whose values this lane holds
   float lp_cur = 0.0f;   // this lane's unit's log prior, of the tile finished last (a hidden read)
   float nlp = 0.0f;      // -scale x log prior of the tile whose values are being written (0 without priors)
   const float pscale = has_prior ? scale : 1.0f, nscale = -scale;
-  char *const yw = reinterpret_cast<char *>(Y + (size_t)(row0 + w * 32) * ldy);
+  char *const yw = reinterpret_cast<char *>(Y + (size_t)wbase * ldy);
   const unsigned ldy4 = (unsigned)ldy * 4u;
-  const int wlast = min(32, nrows - w * 32) - 1;  // the last row of this wave that exists (< 0: none)
-  auto emit_unit = [&](const TileAcc &acc, int n0, auto r_tag, auto checked_tag) __attribute__((always_inline)) {
-    constexpr int r = decltype(r_tag)::value, fr = 8 * (r / 4) + r % 4;
-    constexpr bool kChecked = decltype(checked_tag)::value;
+  const unsigned off_old = (unsigned)(4 * h) * ldy4 + (unsigned)li * 4u, off_new = off_old + 128u;
+  unsigned long long keep_old[4];  // per r % 4: the lanes (of both half-waves) at or past the line boundary
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned bnd = (32u - (((unsigned)(wbase + e) * (unsigned)ldy) & 31u)) & 31u;
+    const unsigned m32 = 0xffffffffu << bnd;
+    keep_old[e] = (unsigned long long)m32 | ((unsigned long long)m32 << 32);
+  }
+  float prev[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) prev[r] = 0.0f;
+  auto final_value = [&](const TileAcc &acc, auto r_tag) __attribute__((always_inline)) -> float {
+    constexpr int r = decltype(r_tag)::value;
     float val = acc[r] - lz4[r / 4][r % 4];
     if constexpr (LOGM) val = fmaxf(val, -46.051701859880914f);  // log(1e-20)
     else val = floor_1e20(__expf(val));
-    val = fmaf(val, pscale, nlp);
-    // The row's part of the address is wave-uniform and stays in scalar registers; the lane's part
-    // is its unit's 4 bytes plus, in the upper half-wave, the distance to the row 4 further on.
-    // (Left to the compiler, the 16 rows' 64-bit addresses were kept in 32 vector registers.)
-    // A wave with fewer than 32 rows only exists in the job that ends the matrix; the rows it lacks
-    // are copies of the last row, computed from the same operands: their stores go to that row,
-    // with the values its own stores carry (row indices are held at wlast).
-    const int r_lo = min(fr, wlast), r_hi = min(fr + 4, wlast);
-    const char *base = yw + (size_t)n0 * 4 + (size_t)((unsigned)r_lo * ldy4);
-    const unsigned off = __umul24((unsigned)h, (unsigned)(r_hi - r_lo) * ldy4) + (unsigned)li * 4u;
-    if constexpr (kChecked) {
-      if (n0 + li < N) store_f32_at(base, off, val);
+    return fmaf(val, pscale, nlp);
+  };
+  // kind 2: the tile at n0 (its values in acc) and the one before it (prev): one whole line per row.
+  // kind 3: the sweep's first tile: the lanes before the boundary, the row's first (partial) line.
+  auto emit_unit = [&](const TileAcc &acc, int n0, auto r_tag, auto kind_tag) __attribute__((always_inline)) {
+    constexpr int r = decltype(r_tag)::value, fr = 8 * (r / 4) + r % 4, kKind = decltype(kind_tag)::value;
+    const float cur = final_value(acc, r_tag);
+    const unsigned long long m = keep_old[r % 4];
+    // the row's part of the address is wave-uniform and stays in scalar registers
+    const char *base = yw + (size_t)(n0 - 32) * 4 + (size_t)(fr * ldy4);
+    if constexpr (kKind == 2) {
+#if AMLIKE_OUTROWS_ABL & 1  // (timing experiment: the whole-line stores of the second sweep are not issued)
+      float keep = select_lanes(cur, prev[r], m);
+      pin_order(keep);
+#else
+      store_f32_at(base, select_lanes(off_new, off_old, m), select_lanes(cur, prev[r], m));
+#endif
     } else {
-      store_f32_at(base, off, val);
+      if (!((m >> lane) & 1ull)) store_f32_at(base, off_new, cur);
     }
+    prev[r] = cur;
+    pin_order(prev[r]);
   };
 
   constexpr int kAhead = 2;
@@ -2156,7 +2194,7 @@ __global__ void __launch_bounds__(512, 2)
   // the kLead - 2 before it each issue all their 16 stores, which are younger than the request
   // waited for at the end and need not have finished.
   auto step = [&](int seq, TileAcc &acc_new, const TileAcc &acc_old, auto sweep2_tag, auto kind_tag,
-                  auto checked_tag, int old_n0, bool stores_counted) __attribute__((always_inline)) {
+                  int old_n0, bool stores_counted) __attribute__((always_inline)) {
     constexpr bool kSweep2 = decltype(sweep2_tag)::value;
     constexpr int kKind = decltype(kind_tag)::value;
     if (!active) {
@@ -2192,7 +2230,7 @@ __global__ void __launch_bounds__(512, 2)
                         u1 = ((mi - kSkip + 1) * NU + NMF - kSkip - 1) / (NMF - kSkip);
           static_for<u1 - u0>([&](auto d) __attribute__((always_inline)) {
             if constexpr (kKind == 1) stats_unit(acc_old, std::integral_constant<int, u0 + decltype(d)::value>());
-            else emit_unit(acc_old, old_n0, std::integral_constant<int, u0 + decltype(d)::value>(), checked_tag);
+            else emit_unit(acc_old, old_n0, std::integral_constant<int, u0 + decltype(d)::value>(), kind_tag);
           });
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -2215,6 +2253,7 @@ __global__ void __launch_bounds__(512, 2)
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
   using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
   TileAcc acc_a, acc_b;
   wait_vector_memory_but<(kLead - 2) * (kMine + 1)>();
   barrier_only();  // tiles 0 and 1 are in LDS
@@ -2223,13 +2262,13 @@ __global__ void __launch_bounds__(512, 2)
   const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   // sweep 1
-  step(0, acc_a, acc_b, std::false_type(), K0(), std::false_type(), 0, false);
+  step(0, acc_a, acc_b, std::false_type(), K0(), 0, false);
   bool in_a = true;  // which set holds the tile finished last
   for (int t = 1; t < ntile; t += 2) {
-    step(t, acc_b, acc_a, std::false_type(), K1(), std::false_type(), 0, false);
+    step(t, acc_b, acc_a, std::false_type(), K1(), 0, false);
     in_a = false;
     if (t + 1 < ntile) {
-      step(t + 1, acc_a, acc_b, std::false_type(), K1(), std::false_type(), 0, false);
+      step(t + 1, acc_a, acc_b, std::false_type(), K1(), 0, false);
       in_a = true;
     }
   }
@@ -2253,22 +2292,36 @@ __global__ void __launch_bounds__(512, 2)
 #ifdef AMLIKE_OUTROWS_STAMPS
   const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
 #endif
-  // sweep 2
-  step(ntile, acc_a, acc_b, std::true_type(), K0(), std::false_type(), 0, false);
-  in_a = true;
-  for (int t = 1; t < ntile; t += 2) {
-    step(ntile + t, acc_b, acc_a, std::true_type(), K2(), std::false_type(), (t - 1) << 5, t >= kLead - 1);
-    in_a = false;
+  // sweep 2 (ntile >= 2): tile 0; tile 1 with the first partial lines of tile 0; then whole lines.
+  // (Stores are counted once this step and the kLead - 2 before it are whole-line steps: a partial
+  // one may be skipped where no lane has anything to write.)
+  step(ntile, acc_a, acc_b, std::true_type(), K0(), 0, false);
+  step(ntile + 1, acc_b, acc_a, std::true_type(), K3(), 0, false);
+  in_a = false;
+  for (int t = 2; t < ntile; t += 2) {
+    step(ntile + t, acc_a, acc_b, std::true_type(), K2(), (t - 1) << 5, t >= kLead);
+    in_a = true;
     if (t + 1 < ntile) {
-      step(ntile + t + 1, acc_a, acc_b, std::true_type(), K2(), std::false_type(), t << 5, t + 1 >= kLead - 1);
-      in_a = true;
+      step(ntile + t + 1, acc_b, acc_a, std::true_type(), K2(), t << 5, t + 1 >= kLead);
+      in_a = false;
     }
   }
   if (active) {
+    // the last tile: its line with the tile before it, then what lies past its boundary; only here
+    // can a lane's unit lie beyond the N the matrix holds (the padding of the last tile)
     mfma_result_gap();
-    static_for<16>([&](auto r) __attribute__((always_inline)) {  // the last tile may be narrower than 32 units
-      if (in_a) emit_unit(acc_a, (ntile - 1) << 5, r, std::true_type());
-      else emit_unit(acc_b, (ntile - 1) << 5, r, std::true_type());
+    const int n0 = (ntile - 1) << 5;
+    static_for<16>([&](auto r_tag) __attribute__((always_inline)) {
+      constexpr int r = decltype(r_tag)::value, fr = 8 * (r / 4) + r % 4;
+      const float cur = in_a ? final_value(acc_a, r_tag) : final_value(acc_b, r_tag);
+      const bool old_lane = (keep_old[r % 4] >> lane) & 1ull;
+      char *row = yw + (size_t)(fr * ldy4) + (size_t)(4 * h) * ldy4;
+      if (old_lane) {
+        *reinterpret_cast<float *>(row + (size_t)(n0 - 32 + li) * 4) = prev[r];
+        if (n0 + li < N) *reinterpret_cast<float *>(row + (size_t)(n0 + li) * 4) = cur;
+      } else if (n0 + li < N) {
+        *reinterpret_cast<float *>(row + (size_t)(n0 + li) * 4) = cur;
+      }
     });
   }
   wait_vector_memory_but<0>();  // no load may still be on its way into LDS when the block ends
@@ -3175,7 +3228,8 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       }
       planes_ready = 0;
       // (the planes carry 1.0 in column in_dim whenever d_wob exists: the 8-wave kernel's bias column)
-      if (s.d_wob && n->out_rows && cur_rows >= 64 && ldo < (1 << 20))  // (24-bit row-offset arithmetic)
+      // (whole-line stores need the line boundary of a row to depend on the row modulo 4 only; two tiles)
+      if (s.d_wob && n->out_rows && cur_rows >= 64 && (ldo & 7) == 0 && ldo < (1 << 24) && s.Nob >= 64)
         rc = LaunchOutRows(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, n->d_log_priors, d_out, ldo,
                            (int)cur_rows, post, prob_scale, st);
       else

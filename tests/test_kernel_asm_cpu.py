@@ -46,17 +46,18 @@ def regs(operand):
     return {int(m.group(1))} if m else set()
 
 
-@pytest.mark.parametrize("kernel,steps", [("nnet_pnorm_rows_kernel", 3), ("nnet_out_rows_kernel", 6)])
-def test_nothing_touches_a_matrix_instructions_registers_right_behind_it(kernel, steps):
+@pytest.mark.parametrize("kernel,steps,parked", [("nnet_pnorm_rows_kernel", 3, 8), ("nnet_out_rows_kernel", 7, 32)])
+def test_nothing_touches_a_matrix_instructions_registers_right_behind_it(kernel, steps, parked):
     """For every matrix instruction and the six instructions behind it: no vector instruction reads
     or writes its result registers, and none writes its operands' registers (an LDS read may name
     them as its destination: its data arrives long after).  `steps`: instances of the 39-instruction
-    step the kernel is known to hold at least."""
+    step the kernel is known to hold at least; `parked`: moves to and from the accumulation registers
+    tolerated in the whole kernel (values parked across a loop)."""
     code = disassemble_kernel(kernel)
     assert sum(l.startswith("v_mfma") for l in code) >= 39 * steps
     # (a handful of index values parked in the accumulation registers across the loop are harmless;
     # moves of matrix results or fragments would number dozens and are caught below anyway)
-    assert sum(l.startswith("v_accvgpr") for l in code) <= 8
+    assert sum(l.startswith("v_accvgpr") for l in code) <= parked
     assert not any(l.startswith("scratch_") for l in code)  # no spills
     bad = []
     for i, l in enumerate(code):

@@ -63,7 +63,9 @@ __global__ void __launch_bounds__(256) row_store_seg(float *y, int ldy, int rows
 // XCD (block id modulo 8) take the strips of one row range after the other (XCD_AWARE), so that at
 // any time the XCD's CUs write neighbouring strips of the same rows through their common L2; or
 // the strips of a range are dealt over all XCDs (XCD_AWARE = 0).
-template <int SLEEP, int XCD_AWARE>
+// LINES = 1: every row's 128 bytes start at a 128-byte boundary (the window of units is shifted per row):
+// the same volume written as whole cache lines whatever the row pitch.
+template <int SLEEP, int XCD_AWARE, int LINES = 0>
 __global__ void __launch_bounds__(512) strip_store(float *y, int ldy, int rows, int ntile, int ranges) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
   const int strips = (ntile + 7) / 8;
@@ -87,16 +89,19 @@ __global__ void __launch_bounds__(512) strip_store(float *y, int ldy, int rows, 
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int fr = 8 * (k / 4) + k % 4;
-      *reinterpret_cast<float *>(base + (size_t)fr * ldy4 + off) = (float)k;
+      char *p = base + (size_t)fr * ldy4 + off;
+      if (LINES) p = reinterpret_cast<char *>((reinterpret_cast<size_t>(base + (size_t)fr * ldy4 + 4u * h * ldy4) & ~(size_t)127) + 4u * li);
+      *reinterpret_cast<float *>(p) = (float)k;
     }
     if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
   }
 }
 
-int main() {
-  const int ldy = 8600, rows = 256 * 256 * 2, ntile = 268;  // 268 * 32 = 8576 <= 8600
+int main(int argc, char **argv) {
+  const int ldy = argc > 1 ? atoi(argv[1]) : 8600, rows = 256 * 256 * 2, ntile = 268;  // 268 * 32 = 8576 <= 8600
   float *y;
   const size_t bytes = (size_t)rows * ldy * 4;
+  printf("row pitch %d floats (%d bytes, %s to 128 bytes)\n", ldy, ldy * 4, ldy % 32 ? "not aligned" : "aligned");
   CHECK(hipMalloc(&y, bytes));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
@@ -166,6 +171,8 @@ int main() {
   run_strip("strips, one range per XCD at a time, s_sleep 24 per step", strip_store<24, 1>, 64);
   run_strip("strips dealt over the XCDs, s_sleep 24 per step", strip_store<24, 0>, 64);
   run_strip("strips, 16 row ranges, one range per XCD at a time", strip_store<0, 1>, 16);
+  run_strip("strips dealt over the XCDs, every row's 128 bytes line-aligned", strip_store<0, 0, 1>, 64);
+  run_strip("the same, s_sleep 24 per step", strip_store<24, 0, 1>, 64);
   CHECK(hipFree(y));
   return 0;
 }
