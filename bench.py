@@ -64,9 +64,10 @@ F16X2_PRODUCTS = 3
 # the chip sustains under the matrix pipe depends on the switching activity of the data)
 MEASURED_F16_MFMA_TFLOPS = 2419.0
 MEASURED_F16_MFMA_TFLOPS_RANDOM = 1700.0
-# (profiles/r2_*_pmc_summary.txt: the current kernel)
-PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 2485900.0, 9292620.0
-PMC_SOURCE = "profiles/r2_i_gmm_diff_pmc_summary.txt"
+# (profiles/r3_x_*_pmc_summary.txt: the current kernel; the counters are in KiB -- the nnet2 output
+# kernel's WRITE_SIZE x 1024 equals its [T x 8600] x 4 bytes exactly)
+PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 2489880.0, 9304190.0
+PMC_SOURCE = "profiles/r3_x_gmm_diff_pmc_summary.txt"
 
 
 def _cpu_model():
@@ -349,8 +350,8 @@ def main():
     traffic = traffic_detail = None
     if args.config == "swbd_tri4" and "gmm_score_diff_kernel<5,2,8,2,f16x2>" in am.kernel_info() \
             and T == PMC_FRAMES:
-        traffic = 2.0 * PMC_FETCH_KB * 1e3 + PMC_WRITE_KB * 1e3
-        traffic_detail = {"fetch_bytes": 2.0 * PMC_FETCH_KB * 1e3, "write_bytes": PMC_WRITE_KB * 1e3,
+        traffic = 2.0 * PMC_FETCH_KB * 1024 + PMC_WRITE_KB * 1024
+        traffic_detail = {"fetch_bytes": 2.0 * PMC_FETCH_KB * 1024, "write_bytes": PMC_WRITE_KB * 1024,
                           "algorithmic_bytes": 4.0 * T * P + 4.0 * T * D,
                           "source": "constants from " + PMC_SOURCE + " (rocprofv3 --pmc passes of this workload and kernel; not re-measured by this run)"}
 

@@ -15,8 +15,8 @@ HBM_PEAK_TBS = 8.0
 # HBM traffic of one forward pass of this workload (256 utterances, 218 541 frames), from rocprofv3
 # --pmc passes (FETCH_SIZE, WRITE_SIZE in KB summed over the pass's kernels; FETCH_SIZE x2 as for the
 # GMM kernel): constants, not re-measured by a bench run.
-PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 6850433.0, 10107758.0
-PMC_SOURCE = "profiles/r2_c_nnet_pmc_summary.txt"
+PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 1639703.0, 9083997.0
+PMC_SOURCE = "profiles/r3_x_nnet_pmc_summary.txt"
 
 
 def run(dev, stream, world, utts_per_gpu=40, steps=10, warmup=2, rank=0):
@@ -60,11 +60,11 @@ def run(dev, stream, world, utts_per_gpu=40, steps=10, warmup=2, rank=0):
                      "traffic": None},
     }
     if T == PMC_FRAMES:
-        res["roofline"]["traffic"] = 2.0 * PMC_FETCH_KB * 1e3 + PMC_WRITE_KB * 1e3
+        res["roofline"]["traffic"] = 2.0 * PMC_FETCH_KB * 1024 + PMC_WRITE_KB * 1024
         res["roofline"]["traffic_detail"] = {
-            "fetch_bytes": 2.0 * PMC_FETCH_KB * 1e3, "write_bytes": PMC_WRITE_KB * 1e3,
+            "fetch_bytes": 2.0 * PMC_FETCH_KB * 1024, "write_bytes": PMC_WRITE_KB * 1024,
             "algorithmic_bytes": 4.0 * T * (40 + P),
-            "source": "constants from " + PMC_SOURCE + " (rocprofv3 --pmc passes of this workload; not "
-                      "re-measured by this run)"}
+            "source": "constants from " + PMC_SOURCE + " (rocprofv3 --pmc passes of this workload, counters in KiB: the output kernel's "
+                      "WRITE_SIZE x 1024 equals its [T x 8600] x 4 bytes exactly; not re-measured by this run)"}
     net.close()
     return res
