@@ -239,3 +239,40 @@ def test_output_layer_and_softmax_in_one_kernel(amlike_device, cus, rows, mode, 
         assert (got.argmax(1) == want.argmax(1)).mean() >= 0.9999
     if mode == nnet.POSTERIORS:
         assert np.allclose(got.sum(1), 1.0, atol=1e-4)
+
+
+@pytest.mark.parametrize("cus", [None, "2"])
+@pytest.mark.parametrize("pitch_pad", [0, 8, 4])
+def test_row_stationary_kernels_on_awkward_row_counts(amlike_device, monkeypatch, cus, pitch_pad):
+    """The 8-wave kernels of the p-norm recipe (hidden layers behind a Normalize, output layer +
+    softmax) on a row count that is no multiple of 32 -- the last wave then takes the matrix's last
+    32 rows -- with the job shapes of the whole chip (all short jobs) and of a two-CU chip (256-row
+    jobs, a staggered short one, a job with inactive waves), and with an output pitch that is the
+    row length (1000 floats: whole-line stores with the boundary moving from row to row), that
+    length + 8, and + 4 (no multiple of 8: the older 4-wave kernel takes over).  Against the oracle
+    on every frame: 1e-3 absolute, same best pdf."""
+    import torch
+    if cus:
+        monkeypatch.setenv("AMLIKE_NNET_OUT_CUS", cus)
+    comps, priors = synth.make_pnorm_nnet(input_dim=40, left=4, right=4, hidden=2000, pnorm_out=200,
+                                          num_hidden=2, num_pdfs=1000, seed=77)
+    net = nnet.AmNnet(comps, priors)
+    rng = np.random.default_rng(78)
+    lens = [77, 333, 1001]
+    utts = [rng.normal(size=(n, 40)).astype(np.float32) for n in lens]
+    ldo = net.OutputDim() + pitch_pad
+    d_in = torch.from_numpy(np.concatenate(utts)).cuda()
+    d_out = torch.full((sum(lens), ldo), 7.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    n = net.ComputeBatchDevice(d_in.data_ptr(), 40, lens, d_out.data_ptr(), ldo, pad_input=True,
+                               mode=nnet.LOGLIKES, prob_scale=0.9)
+    torch.cuda.synchronize()
+    assert n == sum(lens)
+    got = d_out.cpu().numpy()
+    if pitch_pad:
+        assert (got[:, net.OutputDim():] == 7.0).all()  # nothing written between the rows
+    got = got[:, :net.OutputDim()]
+    want = np.concatenate([oracle.nnet_compute(comps, priors, u, True, 2, 0.9) for u in utts])
+    assert np.abs(got - want).max() < 1e-3
+    assert (got.argmax(1) == want.argmax(1)).all()
+    net.close()
