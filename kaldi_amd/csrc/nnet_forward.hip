@@ -2505,6 +2505,11 @@ struct amlike_nnet {
   bool gemm_inline_split = false;  // AMLIKE_NNET_GEMM=inline: bf16x3 GEMM that splits X in its k-loop
   int pnorm_rows = 1;  // AMLIKE_NNET_PNORM_ROWS=0: never the row-stationary affine + p-norm kernel (A/B aid)
   int pnorm_xcd_order = 1;  // AMLIKE_NNET_PNORM_XCD=0: launch-order block mapping in the affine + p-norm kernel (A/B aid)
+  // tuning / testing aids, read from the environment once, when the handle is made
+  int out_cus = 0;            // AMLIKE_NNET_OUT_CUS=<n>: plan the output kernel's jobs for a chip of n CUs
+  bool out_no_stagger = false;  // AMLIKE_NNET_OUT_NO_STAGGER: no short jobs in front
+  bool no_fused_out = false;    // AMLIKE_NNET_NO_FUSED_OUT: output layer and softmax as separate kernels
+  bool no_direct_planes = false;  // AMLIKE_NNET_NO_DIRECT_PLANES: no stage writes its consumer's operand planes
   int rows_norm = 1;  // AMLIKE_NNET_ROWS_NORM=0: the normalisation behind the row-stationary kernel stays a kernel of its own (A/B aid)
   int out_rows = 1;  // AMLIKE_NNET_OUT_ROWS=0: never the 8-wave output-layer + softmax kernel (A/B aid)
   int collapse = 1;  // AMLIKE_NNET_COLLAPSE=0: an affine stage right behind another stays a stage of its own (A/B aid)
@@ -2712,7 +2717,7 @@ static std::vector<uint16_t> BuildOutRowsWeights(const std::vector<float> &w, in
   return out;
 }
 
-static int LaunchOutRows(const Stage &s, const uint4 *xp, size_t xplane, const float *log_priors, float *y,
+static int LaunchOutRows(const amlike_nnet *n, const Stage &s, const uint4 *xp, size_t xplane, const float *log_priors, float *y,
                          int ldy, int rows, int post, float scale, hipStream_t st) {
   if ((post & kPostPrior) && !log_priors) {
     SetError("amlike_nnet_compute: log-likelihoods asked for, but the net has no priors");
@@ -2722,7 +2727,7 @@ static int LaunchOutRows(const Stage &s, const uint4 *xp, size_t xplane, const f
   // multiple of 32 rows; half of the CUs start with a short job (when the short jobs are short),
   // so that the two halves of the chip are in different sweeps from then on.
   int cus = std::max(1, NumComputeUnits());
-  if (const char *e = getenv("AMLIKE_NNET_OUT_CUS")) cus = std::max(1, atoi(e));  // testing aid: job shapes of a smaller chip
+  if (n->out_cus) cus = n->out_cus;  // testing aid: job shapes of a smaller chip
   OutJobs jobs;
   jobs.nbig = (rows / 256 / cus) * cus;
   const int rest = rows - jobs.nbig * 256;
@@ -2733,7 +2738,7 @@ static int LaunchOutRows(const Stage &s, const uint4 *xp, size_t xplane, const f
     nsmall = (rest + jobs.small - 1) / jobs.small;
   }
   jobs.lead = jobs.nbig > 0 && jobs.small <= 128 ? std::min(nsmall, cus / 2) : 0;
-  if (getenv("AMLIKE_NNET_OUT_NO_STAGGER")) jobs.lead = 0;  // tuning aid
+  if (n->out_no_stagger) jobs.lead = 0;  // tuning aid
   const int grid = jobs.nbig + nsmall;
   constexpr int KS = 13;
   const size_t wplane = (size_t)s.Nob * (s.Kp / 8);
@@ -2768,7 +2773,7 @@ static int LaunchOutRows(const Stage &s, const uint4 *xp, size_t xplane, const f
 // or 304; rows of the result 16-byte aligned.
 static bool FusedOutputApplies(const amlike_nnet *n, size_t si, const float *d_out, int ldo, int post) {
   (void)post;
-  if (getenv("AMLIKE_NNET_NO_FUSED_OUT") || n->gemm_f32 || n->gemm_inline_split) return false;
+  if (n->no_fused_out || n->gemm_f32 || n->gemm_inline_split) return false;
   if (si + 2 != n->stages.size()) return false;
   const Stage &s = n->stages[si], &sm = n->stages[si + 1];
   if (s.kind != AMLIKE_AFFINE || s.fuse_gs || sm.kind != AMLIKE_SOFTMAX || s.f16 == 2) return false;
@@ -2778,7 +2783,7 @@ static bool FusedOutputApplies(const amlike_nnet *n, size_t si, const float *d_o
   return true;
 }
 
-static int LaunchOutSoftmax(const Stage &s, const uint4 *xp, size_t xplane, const float *log_priors,
+static int LaunchOutSoftmax(const amlike_nnet *n, const Stage &s, const uint4 *xp, size_t xplane, const float *log_priors,
                             float *y, int ldy, int rows, int post, float scale, hipStream_t st) {
   if ((post & kPostPrior) && !log_priors) {
     SetError("amlike_nnet_compute: log-likelihoods asked for, but the net has no priors");
@@ -2787,7 +2792,7 @@ static int LaunchOutSoftmax(const Stage &s, const uint4 *xp, size_t xplane, cons
   // Jobs: as many full rounds of 256-row jobs as the CUs take evenly, then the rest in equal
   // shares (multiples of 32 rows) so that the last round is short everywhere.
   int cus = std::max(1, NumComputeUnits());
-  if (const char *e = getenv("AMLIKE_NNET_OUT_CUS")) cus = std::max(1, atoi(e));  // testing aid: job shapes of a smaller chip
+  if (n->out_cus) cus = n->out_cus;  // testing aid: job shapes of a smaller chip
   OutJobs jobs;
   jobs.nbig = (rows / 256 / cus) * cus;
   const int rest = rows - jobs.nbig * 256;
@@ -2802,7 +2807,7 @@ static int LaunchOutSoftmax(const Stage &s, const uint4 *xp, size_t xplane, cons
   // with a short job, so that from then on one half of the chip is in its first sweep while
   // the other is in its second.
   jobs.lead = jobs.nbig > 0 && jobs.small <= 128 ? std::min(nsmall, cus / 2) : 0;
-  if (getenv("AMLIKE_NNET_OUT_NO_STAGGER")) jobs.lead = 0;  // tuning aid
+  if (n->out_no_stagger) jobs.lead = 0;  // tuning aid
   const int grid = jobs.nbig + nsmall;
   const size_t wplane = (size_t)s.out_dim * (s.Kp / 8);
   const int npl = s.f16 ? 2 : 3;
@@ -3015,7 +3020,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       // stay inside out_dim.
       const Stage *cons = !last ? &n->stages[si + 1] : nullptr;
       const bool direct = cons && cons->kind == AMLIKE_AFFINE && cons->in_dim == s.out_dim &&
-                          (size_t)kSpliceStageRows * (s.in_dim | 1) * sizeof(float) <= 60 * 1024 && !n->gemm_f32 && !n->gemm_inline_split && !getenv("AMLIKE_NNET_NO_DIRECT_PLANES");
+                          (size_t)kSpliceStageRows * (s.in_dim | 1) * sizeof(float) <= 60 * 1024 && !n->gemm_f32 && !n->gemm_inline_split && !n->no_direct_planes;
       if (direct) {
         // the spliced rows go straight into the consumer's operand planes
         const bool cons_fused = cons->fuse_gs && si + 2 < ns;
@@ -3123,7 +3128,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         AMLIKE_HIP(hipGetLastError());
         const Stage *nx = (norm && si + 2 < ns) ? &n->stages[si + 2] : nullptr;
         if (nx && nx->kind == AMLIKE_AFFINE && nx->f16 == 1 && nx->in_dim == G && G <= 480 && n->rows_norm &&
-            !n->gemm_f32 && !n->gemm_inline_split && !getenv("AMLIKE_NNET_NO_DIRECT_PLANES")) {
+            !n->gemm_f32 && !n->gemm_inline_split && !n->no_direct_planes) {
           const bool nx_fused = nx->fuse_gs && si + 3 < ns;
           const int ckp = nx_fused ? nx->Kpn : nx->Kp;
           const size_t cstride = (size_t)cur_rows * ckp;
@@ -3158,7 +3163,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       // fp16x2 operands read from planes: write its planes directly.
       const Stage *cons = (norm && si + 2 < ns) ? &n->stages[si + 2] : nullptr;
       const bool direct = cons && cons->kind == AMLIKE_AFFINE && cons->f16 == 1 && cons->in_dim == G &&
-                          G <= 480 && !n->gemm_f32 && !n->gemm_inline_split && !getenv("AMLIKE_NNET_NO_DIRECT_PLANES");
+                          G <= 480 && !n->gemm_f32 && !n->gemm_inline_split && !n->no_direct_planes;
       if (direct) {
         const bool cons_fused = cons->fuse_gs && si + 3 < ns;
         const int ckp = cons_fused ? cons->Kpn : cons->Kp;
@@ -3230,10 +3235,10 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       // (the planes carry 1.0 in column in_dim whenever d_wob exists: the 8-wave kernel's bias column)
       // (whole-line stores need the line boundary of a row to depend on the row modulo 4 only; two tiles)
       if (s.d_wob && n->out_rows && cur_rows >= 64 && (ldo & 7) == 0 && ldo < (1 << 24) && s.Nob >= 64)
-        rc = LaunchOutRows(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, n->d_log_priors, d_out, ldo,
+        rc = LaunchOutRows(n, s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, n->d_log_priors, d_out, ldo,
                            (int)cur_rows, post, prob_scale, st);
       else
-        rc = LaunchOutSoftmax(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, n->d_log_priors, d_out, ldo,
+        rc = LaunchOutSoftmax(n, s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, n->d_log_priors, d_out, ldo,
                               (int)cur_rows, post, prob_scale, st);
       if (rc != AMLIKE_OK) return rc;
       cur = d_out;
@@ -3394,6 +3399,10 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
   if (const char *e = getenv("AMLIKE_NNET_COLLAPSE")) n->collapse = e[0] != '0';
   if (const char *e = getenv("AMLIKE_NNET_OUT_ROWS")) n->out_rows = e[0] != '0';
   if (const char *e = getenv("AMLIKE_NNET_ROWS_NORM")) n->rows_norm = e[0] != '0';
+  if (const char *e = getenv("AMLIKE_NNET_OUT_CUS")) n->out_cus = std::max(1, atoi(e));
+  n->out_no_stagger = getenv("AMLIKE_NNET_OUT_NO_STAGGER") != nullptr;
+  n->no_fused_out = getenv("AMLIKE_NNET_NO_FUSED_OUT") != nullptr;
+  n->no_direct_planes = getenv("AMLIKE_NNET_NO_DIRECT_PLANES") != nullptr;
   n->input_dim = comps[0].input_dim;
   int dim = comps[0].input_dim;
   int rc = AMLIKE_OK;
