@@ -44,7 +44,7 @@ def check_against_summary(got, g, name):
     am = got.argmax(1)
     differs = am != g["argmax"]
     tie = (g["best"] - g["second"] < 1e-4) & (am == g["second_idx"])
-    # the measured counts go to gpurun_out/fullsize_argmax_counts.jsonl (quoted in DESIGN.md)
+    # the measured counts go to gpurun_out/fullsize_argmax_counts.jsonl
     record(name, dict(frames=T, best_pdf_differs=int(differs.sum()),
                       of_them_reference_near_ties=int((differs & tie).sum())))
     strict = 1.0 - differs.mean()
