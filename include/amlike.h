@@ -240,7 +240,7 @@ int amlike_gmm_score_raw(amlike_gmm_t *gmm, amlike_xform_t *xf, const float *raw
  * Normalize :578-592, Softmax :905-918, SumGroup :2352-2357, the elementwise
  * Sigmoid :639, Tanh :673, RectifiedLinear :782, SoftHinge :810-816, Power :731-737,
  * Scale :844-850, FixedScale :3103-3109, FixedBias :3171-3177, and Maxout :443-454,
- * Permute :2262-2270, Dct :2802-2830, FixedLinear :2948-2953). */
+ * Permute :2262-2270, Dct :2802-2830, FixedLinear :2948-2953, SpliceMax :2623-2654). */
 enum amlike_component_kind {
   AMLIKE_SPLICE = 1,
   AMLIKE_AFFINE = 2, /* also FixedAffine, and FixedLinear / a BlockAffine written out densely with
@@ -259,16 +259,18 @@ enum amlike_component_kind {
   AMLIKE_FIXED_BIAS = 14,  /* x[c] + bias[c] */
   AMLIKE_MAXOUT = 15,      /* max over consecutive groups of input_dim / output_dim columns, not below -1e20 */
   AMLIKE_PERMUTE = 16,     /* out[sizes[i]] = in[i]: `sizes` holds <Reorder>, a permutation of 0..dim-1 */
-  AMLIKE_DCT = 17          /* per block of const_dim columns a DCT keeping the first output_dim /
+  AMLIKE_DCT = 17,         /* per block of const_dim columns a DCT keeping the first output_dim /
                               (input_dim / const_dim) coefficients; left_context != 0: <Reorder> true */
+  AMLIKE_SPLICE_MAX = 18   /* per column the largest value over frames t - left_context .. t + right_context
+                              (SpliceMaxComponent :2623-2654); counts towards the net's context like SPLICE */
 };
 
 typedef struct amlike_component {
   int32_t kind;          /* enum amlike_component_kind */
   int32_t input_dim;
   int32_t output_dim;
-  int32_t left_context;  /* SPLICE; DCT: the reorder flag */
-  int32_t right_context; /* SPLICE */
+  int32_t left_context;  /* SPLICE, SPLICE_MAX; DCT: the reorder flag */
+  int32_t right_context; /* SPLICE, SPLICE_MAX */
   int32_t const_dim;     /* SPLICE: const_component_dim_; DCT: dct_dim */
   float p;               /* PNORM, POWER: the exponent; SCALE: the factor */
   const float *linear;   /* AFFINE: [output_dim x input_dim] row-major, dense */

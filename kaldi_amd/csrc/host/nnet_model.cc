@@ -68,6 +68,16 @@ static Component ReadComponent(std::istream &is, bool binary) {
     ReadBasicType(is, binary, &c.const_dim);
     ExpectToken(is, binary, end.c_str());
     c.output_dim = (c.input_dim - c.const_dim) * (1 + c.left_context + c.right_context) + c.const_dim;
+  } else if (c.type == "SpliceMaxComponent") {  // :2714-2722
+    c.kind = AMLIKE_SPLICE_MAX;
+    ExpectOneOrTwoTokens(is, binary, token, "<Dim>");
+    ReadBasicType(is, binary, &c.input_dim);
+    ExpectToken(is, binary, "<LeftContext>");
+    ReadBasicType(is, binary, &c.left_context);
+    ExpectToken(is, binary, "<RightContext>");
+    ReadBasicType(is, binary, &c.right_context);
+    ExpectToken(is, binary, end.c_str());
+    c.output_dim = c.input_dim;
   } else if (c.type == "FixedAffineComponent") {  // :3063-3069
     c.kind = AMLIKE_AFFINE;
     ExpectOneOrTwoTokens(is, binary, token, "<LinearParams>");

@@ -80,6 +80,31 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// SpliceMaxComponent (nnet2/nnet-component.cc:2623-2654) with the same edge handling: out row r of
+// utterance u = per column the largest of x[r - left_pad + 0 .. r - left_pad + ns - 1], frame
+// indices clamped to the utterance.  Columns dim .. ld_out-1 are zeroed when zero_pad is set.
+__global__ void __launch_bounds__(256)
+    nnet_pad_splicemax_kernel(const float *__restrict__ in, int ld_in, const UttMap *__restrict__ utts,
+                              int num_utts, int left_pad, int ns, int dim, float *__restrict__ out,
+                              int ld_out, int zero_pad) {
+  const int u = blockIdx.y;
+  const UttMap um = utts[u];
+  for (int r = blockIdx.x; r < um.out_rows; r += gridDim.x) {
+    float *o = out + (size_t)(um.out_off + r) * ld_out;
+    for (int c = threadIdx.x; c < (zero_pad ? ld_out : dim); c += 256) {
+      float v = 0.0f;
+      if (c < dim) {
+        for (int k = 0; k < ns; ++k) {
+          const int src = min(max(r - left_pad + k, 0), um.in_rows - 1);
+          const float x = in[(size_t)(um.in_off + src) * ld_in + c];
+          v = k == 0 ? x : (v < x ? x : v);  // Max(): the other operand where it is larger
+        }
+      }
+      o[c] = v;
+    }
+  }
+}
+
 // Y[M x N] = X[M x K] * W[N x K]^T + bias.  X rows are K-contiguous with stride ldx
 // (multiple of 4, columns K..Kp-1 hold zeros); W is stored [N][Kp], zero padded.
 // 256 threads = 4 waves in a 2 x 2 arrangement, each wave a 64 x 64 tile = 2 x 2 MFMA
@@ -2931,7 +2956,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
   // A net that does not start with a Splice gets a plain copy stage in front, so that
   // every later stage sees an aligned, k-padded buffer.
   const size_t ns = n->stages.size();
-  const bool copy_first = n->stages[0].kind != AMLIKE_SPLICE;
+  const bool copy_first = n->stages[0].kind != AMLIKE_SPLICE && n->stages[0].kind != AMLIKE_SPLICE_MAX;
   std::vector<UttMap> &maps = n->h_utts;
   maps.clear();
   std::vector<int64_t> gather_rows;  // output rows of each gather, in order
@@ -2955,7 +2980,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
     };
     if (copy_first) add_gather(0, 0, 0);
     for (const Stage &s : n->stages)
-      if (s.kind == AMLIKE_SPLICE) {
+      if (s.kind == AMLIKE_SPLICE || s.kind == AMLIKE_SPLICE_MAX) {
         add_gather(pad_done ? 0 : pad_l, pad_done ? 0 : pad_r, s.left + s.right);
         pad_done = true;
       }
@@ -3069,6 +3094,15 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         SetError("amlike_nnet_compute: a net ending in a SpliceComponent needs ldo == output dim");
         return AMLIKE_EINVAL;
       }
+      out_rows = gather_rows[gi++];
+      padded = true;
+    } else if (s.kind == AMLIKE_SPLICE_MAX) {
+      int max_out = 0;
+      for (int u = 0; u < num_utts; ++u) max_out = std::max(max_out, maps[gi * num_utts + u].out_rows);
+      dim3 grid(std::min(max_out, 2048), num_utts);
+      hipLaunchKernelGGL(nnet_pad_splicemax_kernel, grid, dim3(256), 0, st, cur, cur_ld, d_maps + gi * num_utts,
+                         num_utts, padded ? 0 : pad_l, s.left + s.right + 1, s.in_dim, dst, dst_ld, zero_pad);
+      AMLIKE_HIP(hipGetLastError());
       out_rows = gather_rows[gi++];
       padded = true;
     } else if (s.kind == AMLIKE_AFFINE && s.fuse_gs && si + 1 < ns) {
@@ -3452,6 +3486,16 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
         n->right += s.right;
         break;
       }
+      case AMLIKE_SPLICE_MAX:
+        s.left = c.left_context;
+        s.right = c.right_context;
+        if (c.left_context < 0 || c.right_context < 0 || c.input_dim <= 0 || c.output_dim != c.input_dim) {
+          SetError("amlike_nnet_create: bad SpliceMaxComponent %d", i);
+          rc = AMLIKE_EINVAL;
+        }
+        n->left += s.left;
+        n->right += s.right;
+        break;
       case AMLIKE_AFFINE: {
         if (!lin || !lin_bias || c.input_dim <= 0 || c.output_dim <= 0) {
           SetError("amlike_nnet_create: affine component %d without parameters", i);

@@ -22,7 +22,7 @@ KINDS = {"SpliceComponent": 1, "FixedAffineComponent": 2, "AffineComponent": 2,
          "SumGroupComponent": 6, "SigmoidComponent": 7, "TanhComponent": 8,
          "RectifiedLinearComponent": 9, "SoftHingeComponent": 10, "PowerComponent": 11,
          "ScaleComponent": 12, "FixedScaleComponent": 13, "FixedBiasComponent": 14,
-         "MaxoutComponent": 15, "PermuteComponent": 16, "DctComponent": 17}
+         "MaxoutComponent": 15, "PermuteComponent": 16, "DctComponent": 17, "SpliceMaxComponent": 18}
 
 
 def _fp(a):
@@ -86,6 +86,9 @@ def _components_to_c(components):
             keep.append(v)
             a.bias = _fp(v)
             a.input_dim = a.output_dim = len(v)
+        elif t == "SpliceMaxComponent":
+            a.input_dim = a.output_dim = c["dim"]
+            a.left_context, a.right_context = c["left"], c["right"]
         elif t == "DctComponent":
             dct_keep = c.get("dct_keep_dim", 0) or c["dct_dim"]
             a.input_dim, a.const_dim = c["dim"], c["dct_dim"]

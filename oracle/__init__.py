@@ -171,7 +171,8 @@ KINDS = {"SpliceComponent": 1, "FixedAffineComponent": 2, "AffineComponent": 2,
          "RectifiedLinearComponent": 9, "SoftHingeComponent": 10, "PowerComponent": 11,
          "ScaleComponent": 12, "FixedScaleComponent": 13, "FixedBiasComponent": 14,
          "MaxoutComponent": 15, "PermuteComponent": 16, "DctComponent": 17,
-         "BlockAffineComponent": 18, "BlockAffineComponentPreconditioned": 18}
+         "BlockAffineComponent": 18, "BlockAffineComponentPreconditioned": 18,
+         "SpliceMaxComponent": 19}
 
 
 def make_layers(components, struct=NnetLayer):
@@ -216,6 +217,9 @@ def make_layers(components, struct=NnetLayer):
             keep.append(v)
             a.bias = _fp(v)
             a.input_dim = a.output_dim = len(v)
+        elif t == "SpliceMaxComponent":
+            a.input_dim = a.output_dim = c["dim"]
+            a.left_context, a.right_context = c["left"], c["right"]
         elif t == "DctComponent":
             dct_keep = c.get("dct_keep_dim", 0) or c["dct_dim"]
             a.input_dim, a.const_dim = c["dim"], c["dct_dim"]

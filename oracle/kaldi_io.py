@@ -292,6 +292,11 @@ class Reader:
             self.expect("<DerivSum>"); self.vector(binary)
             self.expect("<Count>"); self.float32(binary)
             self.expect("</%s>" % t)
+        elif t == "SpliceMaxComponent":  # :2714-2722
+            self.expect("<Dim>"); c["dim"] = self.int32(binary)
+            self.expect("<LeftContext>"); c["left"] = self.int32(binary)
+            self.expect("<RightContext>"); c["right"] = self.int32(binary)
+            self.expect("</SpliceMaxComponent>")
         elif t == "MaxoutComponent":  # :481-487
             self.expect("<InputDim>"); c["input_dim"] = self.int32(binary)
             self.expect("<OutputDim>"); c["output_dim"] = self.int32(binary)
@@ -609,6 +614,11 @@ def write_component(f, binary, comp):
         write_token(f, binary, "<ValueSum>"); write_vector(f, binary, np.zeros(0), double=True)
         write_token(f, binary, "<DerivSum>"); write_vector(f, binary, np.zeros(0), double=True)
         write_token(f, binary, "<Count>"); write_double(f, binary, 0.0)
+        write_token(f, binary, "</%s>" % t)
+    elif t == "SpliceMaxComponent":  # :2724-2733
+        write_token(f, binary, "<Dim>"); write_int32(f, binary, comp["dim"])
+        write_token(f, binary, "<LeftContext>"); write_int32(f, binary, comp["left"])
+        write_token(f, binary, "<RightContext>"); write_int32(f, binary, comp["right"])
         write_token(f, binary, "</%s>" % t)
     elif t == "MaxoutComponent":  # :489-496
         write_token(f, binary, "<InputDim>"); write_int32(f, binary, comp["input_dim"])

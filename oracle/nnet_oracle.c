@@ -23,7 +23,7 @@
 enum { K_SPLICE = 1, K_AFFINE = 2, K_PNORM = 3, K_NORMALIZE = 4, K_SOFTMAX = 5,
        K_SUMGROUP = 6, K_SIGMOID = 7, K_TANH = 8, K_RELU = 9, K_SOFTHINGE = 10, K_POWER = 11,
        K_SCALE = 12, K_FIXED_SCALE = 13, K_FIXED_BIAS = 14, K_MAXOUT = 15, K_PERMUTE = 16,
-       K_DCT = 17, K_BLOCK_AFFINE = 18 };
+       K_DCT = 17, K_BLOCK_AFFINE = 18, K_SPLICE_MAX = 19 };
 
 typedef struct {
   int32_t kind, input_dim, output_dim;
@@ -38,11 +38,11 @@ typedef struct {
 } oracle_layer;
 
 /* nnet2/nnet-nnet.cc:39-53  Nnet::LeftContext / RightContext: sums over components
- * (only SpliceComponent has a non-zero context, nnet2/nnet-component.h). */
+ * (only SpliceComponent and SpliceMaxComponent have a non-zero context, nnet2/nnet-component.h). */
 void oracle_nnet_context(const oracle_layer *L, int n, int *left, int *right) {
   *left = *right = 0;
   for (int i = 0; i < n; i++)
-    if (L[i].kind == K_SPLICE) { *left += L[i].left_context; *right += L[i].right_context; }
+    if (L[i].kind == K_SPLICE || L[i].kind == K_SPLICE_MAX) { *left += L[i].left_context; *right += L[i].right_context; }
 }
 
 /* nnet2/nnet-component.cc:2411-2471  SpliceComponent::Propagate (one chunk):
@@ -58,6 +58,23 @@ static void splice(const oracle_layer *l, const float *in, int rows_in, float *o
       memcpy(out + (size_t)r * od + ns * dim, in + (size_t)r * l->input_dim + dim,
              l->const_dim * sizeof(float));
   }
+}
+
+/* nnet2/nnet-component.cc:2623-2654  SpliceMaxComponent::Propagate (one chunk): out row r starts
+ * as in row r and takes Max() with in rows r+1 .. r+L+R (matrix/kaldi-matrix.cc Max: the other
+ * matrix's element where it is larger). */
+static void splice_max(const oracle_layer *l, const float *in, int rows_in, float *out) {
+  int ns = l->left_context + l->right_context + 1, dim = l->input_dim;
+  int rows_out = rows_in - l->left_context - l->right_context;
+  for (int r = 0; r < rows_out; r++)
+    for (int c = 0; c < dim; c++) {
+      float v = in[(size_t)r * dim + c];
+      for (int k = 1; k < ns; k++) {
+        float x = in[(size_t)(r + k) * dim + c];
+        if (v < x) v = x;
+      }
+      out[(size_t)r * dim + c] = v;
+    }
 }
 
 /* nnet2/nnet-component.cc:1123-1131 (Affine: out = bias rows; out += in * W^T) and
@@ -301,11 +318,12 @@ int oracle_nnet_compute(const oracle_layer *L, int n, const float *priors, int n
   for (int i = 0; i < n; i++) {
     const oracle_layer *l = &L[i];
     if (l->input_dim != dim) { free(cur); return 1; }
-    int rows_out = rows - (l->kind == K_SPLICE ? l->left_context + l->right_context : 0);
+    int rows_out = rows - (l->kind == K_SPLICE || l->kind == K_SPLICE_MAX ? l->left_context + l->right_context : 0);
     if (rows_out <= 0) { free(cur); return 1; }
     float *next = (float *)malloc((size_t)rows_out * l->output_dim * sizeof(float));
     switch (l->kind) {
       case K_SPLICE: splice(l, cur, rows, next); break;
+      case K_SPLICE_MAX: splice_max(l, cur, rows, next); break;
       case K_AFFINE: affine(l, cur, rows, next); break;
       case K_PNORM: pnorm(l, cur, rows, next); break;
       case K_NORMALIZE: normalize(l, cur, rows, next); break;

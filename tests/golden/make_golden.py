@@ -17,7 +17,8 @@ Files written (all small):
   nnet_c.mdl nnet_c_feats.ark nnet_c_post.ark nnet_c_post_nopad.ark   Dct, FixedScale, FixedBias, SoftHinge,
                                                Permute, FixedLinear, Maxout, Scale, Power, BlockAffine
   nnet_d.mdl nnet_d_feats.ark nnet_d_post.ark  Dct with <Reorder> (whole and truncated), the Power branches
-               (python tests/golden/make_golden.py nnet_cd   regenerates these two only)
+  nnet_e.mdl nnet_e_feats.ark nnet_e_post.ark nnet_e_post_nopad.ark   Splice and SpliceMax (two context components)
+               (python tests/golden/make_golden.py nnet_cd   regenerates these three only)
   cm_feats.ark  cm_feats_expanded.ark          CompressedMatrix archive and its expansion
   gsel.mdl gsel_feats.ark gsel_top5.txt        DiagGmm::GaussianSelection, 5 of 64 per frame
   xf_feats.ark xf_mats.ark                     13-dim features; "lda" 40x92, "lin" 40x91, "fmllr" 40x41
@@ -125,6 +126,20 @@ def nnet_cd_cases():
     ]
     pri_d = rng.dirichlet(np.ones(8)).astype(np.float32)
     nnet_case("nnet_d", comps_d, pri_d, [("d1", rng.standard_normal((29, 8)).astype(np.float32))], full=False)
+    # nnet_e: SpliceMax between an affine stage and the rest, a Splice in front: two context
+    # components, padded and unpadded
+    comps_e = [
+        dict(type="SpliceComponent", input_dim=9, left=1, right=2, const_dim=0),
+        aff("AffineComponent", 36, 14), dict(type="TanhComponent", dim=14),
+        dict(type="SpliceMaxComponent", dim=14, left=2, right=1),
+        aff("AffineComponent", 14, 11), dict(type="SoftmaxComponent", dim=11),
+    ]
+    pri_e = rng.dirichlet(np.ones(11)).astype(np.float32)
+    feats_e = [("e1", rng.standard_normal((31, 9)).astype(np.float32)),
+               ("e2", rng.standard_normal((8, 9)).astype(np.float32))]
+    nnet_case("nnet_e", comps_e, pri_e, feats_e, full=False)
+    oracle.ref_driver("nnet-compute", path("nnet_e.mdl"), "ark:" + path("nnet_e_feats.ark"),
+                      "ark:" + path("nnet_e_post_nopad.ark"), "0", "0")
 
 
 def main():

@@ -286,7 +286,7 @@ def test_nnet_am_compute_binary(nnet_files, apply_log, pad):
             assert (l.argmax(1) == want.argmax(1)).mean() >= 0.9999
 
 
-@pytest.mark.parametrize("tag", ["nnet_c", "nnet_d"])
+@pytest.mark.parametrize("tag", ["nnet_c", "nnet_d", "nnet_e"])
 @pytest.mark.parametrize("binary", [True, False])
 def test_nnet_am_compute_reads_every_forward_component(tmp_path, tag, binary):
     """The model reader of the binaries on the networks that hold Dct, FixedScale, FixedBias,

@@ -85,10 +85,10 @@ def test_nnet_other_components_vs_golden(amlike_device):
         assert np.abs(got - want[key]).max() <= 1e-5
 
 
-@pytest.mark.parametrize("tag", ["nnet_c", "nnet_d"])
+@pytest.mark.parametrize("tag", ["nnet_c", "nnet_d", "nnet_e"])
 def test_nnet_remaining_components_vs_golden(amlike_device, tag):
     """Dct (plain, reordered, truncated), FixedScale, FixedBias, SoftHinge, Permute, FixedLinear,
-    Maxout, Scale, Power and BlockAffine: the reference's posteriors, 1e-5 absolute, for one
+    Maxout, Scale, Power, BlockAffine and SpliceMax: the reference's posteriors, 1e-5 absolute, for one
     utterance at a time and for all of them in one batch."""
     import torch
     comps, priors = load_am_nnet(tag + ".mdl")
@@ -100,7 +100,7 @@ def test_nnet_remaining_components_vs_golden(amlike_device, tag):
         assert got.shape == want[key].shape
         assert np.abs(got - want[key]).max() <= 1e-5
         assert (got.argmax(1) == want[key].argmax(1)).all()
-    if tag == "nnet_c":
+    if tag != "nnet_d":
         nopad = dict(load_ark(tag + "_post_nopad.ark"))
         for key, feats in items:
             got = net.Compute(feats, pad_input=False, mode=nnet.POSTERIORS)

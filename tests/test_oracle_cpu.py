@@ -95,10 +95,10 @@ def test_nnet_other_components_vs_golden():
         np.testing.assert_allclose(got.sum(1), 1.0, atol=1e-5)
 
 
-@pytest.mark.parametrize("tag,nopad", [("nnet_c", True), ("nnet_d", False)])
+@pytest.mark.parametrize("tag,nopad", [("nnet_c", True), ("nnet_d", False), ("nnet_e", True)])
 def test_nnet_remaining_components_vs_golden(tag, nopad):
     """Dct (plain, reordered, truncated), FixedScale, FixedBias, SoftHinge, Permute, FixedLinear,
-    Maxout, Scale, Power (every branch of ApplyPowAbs) and BlockAffine against the reference."""
+    Maxout, Scale, Power (every branch of ApplyPowAbs), BlockAffine and SpliceMax against the reference."""
     comps, priors = load_am_nnet(tag + ".mdl")
     want = dict(load_ark(tag + "_post.ark"))
     for key, feats in load_ark(tag + "_feats.ark"):
@@ -107,7 +107,7 @@ def test_nnet_remaining_components_vs_golden(tag, nopad):
         assert np.abs(got - want[key]).max() <= ORACLE_TOL
     if nopad:
         want = dict(load_ark(tag + "_post_nopad.ark"))
-        assert want["c2"].shape[0] == 1  # 3 frames, one of context on each side
+        assert min(v.shape[0] for v in want.values()) <= 2  # an utterance barely longer than the context
         for key, feats in load_ark(tag + "_feats.ark"):
             got = oracle.nnet_compute(comps, priors, feats, pad_input=False, mode=0)
             assert got.shape == want[key].shape
