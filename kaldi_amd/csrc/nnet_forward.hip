@@ -1643,6 +1643,9 @@ __global__ void __launch_bounds__(256, 1)
 #ifndef AMLIKE_ROWS_ABL
 #define AMLIKE_ROWS_ABL 0
 #endif
+#ifndef AMLIKE_ROWS_ONECHAIN  // 1: all three partial products in one accumulator chain (measured 1.6 % faster than two)
+#define AMLIKE_ROWS_ONECHAIN 1
+#endif
 #ifdef AMLIKE_ROWS_STAMPS  // diagnostic build: clock ticks per part of a step, waves 0 and 4 of block 0
 __device__ unsigned long long g_rows_stamps[16];
 #endif
@@ -1737,7 +1740,11 @@ __global__ void __launch_bounds__(512, 2)
   // the vector work on value r of a finished tile
   auto square_unit = [&](const TileAcc &acc, auto r_tag) __attribute__((always_inline)) {
     constexpr int r = decltype(r_tag)::value;
+#if AMLIKE_ROWS_ONECHAIN
+    const float v = acc.x[r];
+#else
     const float v = acc.x[r] + acc.y[r];
+#endif
     ss[r & 7] = fmaf(v, v, ss[r & 7]);
     pin_order(ss[r & 7]);
   };
@@ -1754,7 +1761,16 @@ __global__ void __launch_bounds__(512, 2)
     }
     float4 lo = make_float4(sqrtf(ss[0]), sqrtf(ss[1]), sqrtf(ss[2]), sqrtf(ss[3]));
     float4 hi = make_float4(sqrtf(ss[4]), sqrtf(ss[5]), sqrtf(ss[6]), sqrtf(ss[7]));
-    if (rl < nrows) {
+    if (nout.p) {
+      // The rows are normalised by the epilogue: until then Y is this kernel's scratch, laid out so
+      // that a half-wave's 32 lanes write (and later read back) 512 consecutive bytes: 16-byte
+      // element (2 octet + half) * M + row.  (Groups past G come from all-zero rows of W: zeros.)
+      float4 *yt = reinterpret_cast<float4 *>(Y) + (size_t)(2 * (2 * sup + h)) * M + (row0 + rl);
+      if (rl < nrows) {
+        yt[0] = lo;
+        yt[M] = hi;
+      }
+    } else if (rl < nrows) {
       float *o = Y + (size_t)(row0 + rl) * ldy + g0;
       if (g0 + 8 <= G) {
         *reinterpret_cast<float4 *>(o) = lo;
@@ -1832,9 +1848,15 @@ __global__ void __launch_bounds__(512, 2)
         // order within a k-step: cross product, high parts, cross product (y, x, y)
         constexpr int j = decltype(j_tag)::value, mi = ks * NPROD + j;
         // the fragments of X live in the accumulation registers, the accumulators in the ordinary ones
+#if AMLIKE_ROWS_ONECHAIN  // (A/B aid: all three products in one chain)
+        if constexpr (j == 0) mfma_f16_asm_vacc<ks == 0>(acc_new.x, wf[slot][1], xf[ks][0]);
+        else if constexpr (j == 1) mfma_f16_asm_vacc<false>(acc_new.x, wf[slot][0], xf[ks][1]);
+        else mfma_f16_asm_vacc<false>(acc_new.x, wf[slot][0], xf[ks][0]);
+#else
         if constexpr (j == 0) mfma_f16_asm_vacc<ks == 0>(acc_new.y, wf[slot][1], xf[ks][0]);
         else if constexpr (j == 1) mfma_f16_asm_vacc<ks == 0>(acc_new.x, wf[slot][0], xf[ks][0]);
         else mfma_f16_asm_vacc<false>(acc_new.y, wf[slot][0], xf[ks][1]);
+#endif
         // The previous tile's values are read from the fourth matrix instruction of the step on: by
         // then the last matrix instruction of the previous step has long delivered its result.
         if constexpr (kWork && !(AMLIKE_ROWS_ABL & 1) && mi >= kSkip) {  // (bit 0, timing experiment: no vector work)
@@ -1906,36 +1928,34 @@ __global__ void __launch_bounds__(512, 2)
   if (nout.p) {
     // The NormalizeComponent behind the p-norm, and the next affine stage's fp16x2 operand planes
     // (nnet2/nnet-component.cc:578-592; the layout nnet_normalize_planes_kernel writes): the wave
-    // reads its 32 rows back (they are in L2), scales each by 1 / sqrt(max(sum of squares / G,
-    // 2^-66)) and writes plane q, octet o, row r as 16 bytes; half-wave h takes the octets o = h
-    // (mod 2).  (The stores of Y above have finished: the wait counted them.)
+    // reads back what its lanes wrote (it is in L2; every lane its own values, in the scratch
+    // layout above), scales each row by 1 / sqrt(max(sum of squares / G, 2^-66)) and writes plane
+    // q, octet o, row r as 16 bytes; half-wave h takes the octets o = h (mod 2).  (The stores above
+    // have finished: the wait counted them.)
     const float tot = rowsq + __shfl_xor(rowsq, 32);
     const float f = 1.0f / sqrtf(fmaxf(tot / G, 1.3552527156068805e-20f));
     if (rl < nrows) {
-      const float *x = Y + (size_t)(row0 + rl) * ldy;
+      const float4 *yt = reinterpret_cast<const float4 *>(Y) + (row0 + rl);
       uint4 *o = reinterpret_cast<uint4 *>(nout.p);
       const size_t pstride = nout.stride >> 3;
-      // four octets at a time: their eight loads are in flight together (a lane reads its own
-      // row, so every load instruction touches 32 lines of L2 and its latency is what counts)
-      const int kp8 = nout.Kp >> 3;
-      for (int oct0 = h; oct0 < kp8; oct0 += 8) {
-        float4 a[4], bq[4];
+      const int kp8 = nout.Kp >> 3, ny8 = Npad / 80;  // octets of the planes; octets this kernel wrote
+      // four octets at a time: their eight loads are in flight together (larger batches measured
+      // the same: the epilogue costs what its 2 x 182 MB of traffic cost, in bursts at the job ends)
+      constexpr int kBatch = 4;
+      for (int oct0 = h; oct0 < kp8; oct0 += 2 * kBatch) {
+        float4 a[kBatch], bq[kBatch];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int c0 = (oct0 + 2 * u) * 8;
-          if (c0 + 8 <= G) {
-            a[u] = *reinterpret_cast<const float4 *>(x + c0);
-            bq[u] = *reinterpret_cast<const float4 *>(x + c0 + 4);
+        for (int u = 0; u < kBatch; ++u) {
+          const int oct = oct0 + 2 * u;
+          if (oct < ny8) {
+            a[u] = yt[(size_t)(2 * oct) * M];
+            bq[u] = yt[(size_t)(2 * oct + 1) * M];
           } else {
-            float t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = c0 + j < G ? x[c0 + j] : 0.0f;
-            a[u] = make_float4(t[0], t[1], t[2], t[3]);
-            bq[u] = make_float4(t[4], t[5], t[6], t[7]);
+            a[u] = bq[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kBatch; ++u) {
           const int oct = oct0 + 2 * u, c0 = oct * 8;
           if (oct >= kp8) break;
           float t[8] = {a[u].x * f, a[u].y * f, a[u].z * f, a[u].w * f, bq[u].x * f, bq[u].y * f, bq[u].z * f, bq[u].w * f};

@@ -52,12 +52,13 @@ def test_nothing_touches_a_matrix_instructions_registers_right_behind_it(kernel,
     or writes its result registers, and none writes its operands' registers (an LDS read may name
     them as its destination: its data arrives long after).  `steps`: instances of the 39-instruction
     step the kernel is known to hold at least; `parked`: moves to and from the accumulation registers
-    tolerated in the whole kernel (values parked across a loop)."""
+    tolerated up to the last matrix instruction (values parked across a loop)."""
     code = disassemble_kernel(kernel)
     assert sum(l.startswith("v_mfma") for l in code) >= 39 * steps
     # (a handful of index values parked in the accumulation registers across the loop are harmless;
     # moves of matrix results or fragments would number dozens and are caught below anyway)
-    assert sum(l.startswith("v_accvgpr") for l in code) <= parked
+    last_mfma = max(i for i, l in enumerate(code) if l.startswith("v_mfma"))
+    assert sum(l.startswith("v_accvgpr") for l in code[:last_mfma]) <= parked  # (an epilogue may use the dead fragments' registers)
     assert not any(l.startswith("scratch_") for l in code)  # no spills
     bad = []
     for i, l in enumerate(code):
