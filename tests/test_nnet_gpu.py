@@ -276,3 +276,30 @@ def test_row_stationary_kernels_on_awkward_row_counts(amlike_device, monkeypatch
     assert np.abs(got - want).max() < 1e-3
     assert (got.argmax(1) == want.argmax(1)).all()
     net.close()
+
+
+def test_affine_behind_affine_is_folded_into_one_stage(amlike_device, monkeypatch):
+    """FixedAffine + Affine (+ a third affine) become one stage when the engine is built, as
+    nnet-am-copy --collapse would make them (nnet2/nnet-nnet.cc:624-663); the answers agree with the
+    stages kept apart (AMLIKE_NNET_COLLAPSE=0) to rounding, and with the oracle, which runs the
+    components one by one."""
+    rng = np.random.default_rng(91)
+
+    def aff(kind, n_in, n_out):
+        return dict(type=kind, linear=(rng.normal(size=(n_out, n_in)) / np.sqrt(n_in)).astype(np.float32),
+                    bias=rng.normal(size=n_out).astype(np.float32))
+    comps = [dict(type="SpliceComponent", input_dim=12, left=2, right=2, const_dim=0),
+             aff("FixedAffineComponent", 60, 60), aff("AffineComponent", 60, 48),
+             aff("AffineComponentPreconditioned", 48, 80),
+             dict(type="PnormComponent", input_dim=80, output_dim=8, p=2.0),
+             dict(type="NormalizeComponent", dim=8), aff("AffineComponent", 8, 30),
+             dict(type="SoftmaxComponent", dim=30)]
+    priors = np.full(30, 1 / 30, np.float32)
+    x = rng.normal(size=(150, 12)).astype(np.float32)
+    folded = nnet.AmNnet(comps, priors).Compute(x, mode=nnet.LOGLIKES)
+    monkeypatch.setenv("AMLIKE_NNET_COLLAPSE", "0")
+    apart = nnet.AmNnet(comps, priors).Compute(x, mode=nnet.LOGLIKES)
+    np.testing.assert_allclose(folded, apart, rtol=0, atol=5e-5)
+    want = oracle.nnet_compute(comps, priors, x, True, nnet.LOGLIKES, 1.0)
+    assert np.abs(folded - want).max() < 1e-3
+    assert (folded.argmax(1) == want.argmax(1)).all()
