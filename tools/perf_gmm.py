@@ -31,6 +31,7 @@ fpad[:, :D] = feats
 d_feats = torch.from_numpy(fpad).cuda()
 d_out = torch.empty((T, P), dtype=torch.float32, device="cuda")
 flop = 2.0 * (2 * D + 1) * G * T
+first_out = None
 for v in variants:
     if ":" in v:
         os.environ["AMLIKE_GMM_MODE"], v = v.split(":")
@@ -42,6 +43,11 @@ for v in variants:
         am.Poll()
     except Exception as e:
         print('poll:', e)
+    got = d_out.cpu().numpy()
+    if first_out is None:
+        first_out = got
+    else:  # the variants against the first one named
+        print("   max |difference| to the first variant's scores: %.3g" % float(np.abs(got - first_out).max()))
     print("%s  %s\n   %.3f ms/launch  %.3f Mframes/s  %.1f TFLOP/s (%.1f%% of 157.3)" % (
         v, am.kernel_info(), ms, T / ms / 1e3, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100), flush=True)
     am.close()
