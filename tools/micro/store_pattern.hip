@@ -64,7 +64,8 @@ __global__ void __launch_bounds__(256) row_store_seg(float *y, int ldy, int rows
 // any time the XCD's CUs write neighbouring strips of the same rows through their common L2; or
 // the strips of a range are dealt over all XCDs (XCD_AWARE = 0).
 // LINES = 1: every row's 128 bytes start at a 128-byte boundary (the window of units is shifted per row):
-// the same volume written as whole cache lines whatever the row pitch.
+// the same volume written as whole cache lines whatever the row pitch.  LINES = 2: the same lines,
+// each filled by four 16-byte stores of the two lanes that own the row (quarter lines per instruction).
 template <int SLEEP, int XCD_AWARE, int LINES = 0>
 __global__ void __launch_bounds__(512) strip_store(float *y, int ldy, int rows, int ntile, int ranges) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
@@ -86,6 +87,16 @@ __global__ void __launch_bounds__(512) strip_store(float *y, int ldy, int rows, 
   const unsigned ldy4 = ldy * 4u, off = 4u * h * ldy4 + 4u * li;
   for (int r = r0; r + 32 <= r0 + per; r += 32) {
     char *base = reinterpret_cast<char *>(y + (size_t)r * ldy + tile * 32);
+    if (LINES == 2) {
+      // a lane owns a row: four 16-byte stores per lane, each instruction 32 bytes of every row's
+      // line-aligned 128 bytes (lanes li and li + 32), the four together the whole line
+      char *line = reinterpret_cast<char *>(reinterpret_cast<size_t>(base + (size_t)li * ldy4) & ~(size_t)127);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<float4 *>(line + (8 * j + 4 * h) * 4) = make_float4((float)j, 1.0f, 2.0f, 3.0f);
+      if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int fr = 8 * (k / 4) + k % 4;
@@ -173,6 +184,8 @@ int main(int argc, char **argv) {
   run_strip("strips, 16 row ranges, one range per XCD at a time", strip_store<0, 1>, 16);
   run_strip("strips dealt over the XCDs, every row's 128 bytes line-aligned", strip_store<0, 0, 1>, 64);
   run_strip("the same, s_sleep 24 per step", strip_store<24, 0, 1>, 64);
+  run_strip("line-aligned, a lane per row: 4 x 16-byte stores fill a line", strip_store<0, 0, 2>, 64);
+  run_strip("the same, s_sleep 24 per step", strip_store<24, 0, 2>, 64);
   CHECK(hipFree(y));
   return 0;
 }
