@@ -43,6 +43,8 @@ for v in variants:
         am.Poll()
     except Exception as e:
         print('poll:', e)
+    print("%s  %s\n   %.3f ms/launch  %.3f Mframes/s  %.1f TFLOP/s (%.1f%% of 157.3)" % (
+        v, am.kernel_info(), ms, T / ms / 1e3, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100), flush=True)
     got = d_out.cpu().numpy()
     if first_out is None:
         first_out = got
@@ -50,6 +52,4 @@ for v in variants:
         d = np.abs(got - first_out)
         print("   against the first variant's scores: max |difference| %.3g, relative to max(1, |score|) %.3g"
               % (float(d.max()), float((d / np.maximum(1.0, np.abs(first_out))).max())))
-    print("%s  %s\n   %.3f ms/launch  %.3f Mframes/s  %.1f TFLOP/s (%.1f%% of 157.3)" % (
-        v, am.kernel_info(), ms, T / ms / 1e3, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100), flush=True)
     am.close()
