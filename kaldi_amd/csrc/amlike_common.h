@@ -37,6 +37,30 @@ int BindHandle(const H *h) {
 // allocates nothing (gmm_score.hip); called by amlike_init with `device` current.
 int SetupNoAllocScratch(int device);
 
+// Control words in device memory (overflow counts, "out of range" and "not finite" flags): a
+// kernel raises them, later kernels of the same call decide by them what to run, the host reads
+// them back.  The chip's compute dies each have an L2 of their own, and an ordinary load may be
+// served from a die's copy of the line taken before another die's atomic changed the word (seen
+// as, rarely, a repair pass that found an empty list, or a flag the host never saw).  These
+// accesses therefore go at system scope, past the L2s, for readers and writers alike.
+#if defined(__HIPCC__)
+__device__ __forceinline__ int ctl_load(const int *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void ctl_store(int *p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ int ctl_add(int *p, int v) {
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void ctl_or(int *p, int v) {
+  (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+// Zeroes n control words by a kernel on `st` (the same kind of store as above; a fill
+// by the copy engine or a fill node of a graph is not seen by every later atomic).
+int ClearWords(int *d_words, int n, hipStream_t st);
+
 // Growable device buffer owned by a handle.  Never shrinks.
 struct DeviceBuffer {
   void *ptr = nullptr;

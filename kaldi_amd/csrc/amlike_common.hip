@@ -167,6 +167,21 @@ bool IsPageLocked(const void *p) {
 
 }  // namespace
 
+__global__ void clear_words_kernel(int *words, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) ctl_store(words + i, 0);
+}
+
+int ClearWords(int *d_words, int n, hipStream_t st) {
+  if (!d_words || n <= 0) {
+    SetError("ClearWords: bad argument");
+    return AMLIKE_EINVAL;
+  }
+  hipLaunchKernelGGL(clear_words_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_words, n);
+  AMLIKE_HIP(hipGetLastError());
+  return AMLIKE_OK;
+}
+
 int CopyMatrixToHost(float *out, size_t ldo, const float *d_src, int rows, int cols, hipStream_t st) {
   const size_t row_bytes = (size_t)cols * sizeof(float), total = row_bytes * rows;
   const bool staged = total >= 2 * kStageBytes && !IsPageLocked(out) && !getenv("AMLIKE_NO_STAGED_COPY");

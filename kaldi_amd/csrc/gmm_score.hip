@@ -141,7 +141,7 @@ __device__ __forceinline__ void wait_vector_memory() {
 
 __device__ __forceinline__ bool guard_skips(const int *ctl, int fix_cap, int guard) {
   if (guard == 0) return false;
-  const int range = __builtin_nontemporal_load(ctl + 1), count = __builtin_nontemporal_load(ctl);
+  const int range = ctl_load(ctl + 1), count = ctl_load(ctl);
   const bool fallback = range != 0 || count > fix_cap;
   return guard == 1 ? range != 0 : !fallback;
 }
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(64 * W, (64 * W) / 256)
             const float v = M + kLn2 * fast_log2(S);
             if (row_ok) {
               orow[col] = v;
-              if (!(fabsf(v) <= 3.0e38f)) atomicOr(ar.flag, 1);
+              if (!(fabsf(v) <= 3.0e38f)) ctl_or(ar.flag, 1);
             }
           } else if (col != kColDiscard) {  // one part of a pdf split over several waves
             if (row_ok) {
@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(256)
   uint4 *o = bx + ((size_t)(ft * KS + s) * 2) * 64 + lane;
   o[0] = pack(p1);
   o[64] = pack(p2);
-  if (out_of_range) atomicOr(ctl + 1, 1);
+  if (out_of_range) ctl_or(ctl + 1, 1);
 }
 
 // ABL (timing experiments only, never dispatched in production): bit0 no output
@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(64 * W, OCC)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc_cur[nt] = acc_next[nt];
   }
-  if (bad) atomicOr(ar.flag, 1);
+  if (bad) ctl_or(ar.flag, 1);
 }
 
 
@@ -947,7 +947,7 @@ __global__ void __launch_bounds__(64 * W, OCC)
   // feature fragments of the first kPre k-steps (and the gconsts, where they come from LDS)
   // have been requested by the caller (preload), as early as the staging protocol allows.
   auto report_overflow = [&](int row, int col) {
-    const int kk = atomicAdd(ar.ctl, 1);
+    const int kk = ctl_add(ar.ctl, 1);
     if (kk < ar.fix_cap) ar.fix_list[kk] = make_int2(row, col);
   };
 
@@ -1335,7 +1335,7 @@ __global__ void __launch_bounds__(64 * W, OCC)
 }
 
 __global__ void gmm_clear_ctl_kernel(int *ctl) {
-  if (threadIdx.x < 2) ctl[threadIdx.x] = 0;
+  if (threadIdx.x < 2) ctl_store(ctl + threadIdx.x, 0);
 }
 
 // Recomputes the listed (frame, pdf) pairs in plain fp32 with the reference's own
@@ -1345,8 +1345,8 @@ __global__ void __launch_bounds__(256)
                    const float *__restrict__ gconsts, const float *__restrict__ miv,
                    const float *__restrict__ iv, const int32_t *__restrict__ offsets, int dim,
                    const float *__restrict__ feats, int ld, float *out, int ldo, int *flag) {
-  if (ctl[1] != 0) return;
-  const int n = ctl[0];
+  if (ctl_load(ctl + 1) != 0) return;
+  const int n = ctl_load(ctl);
   if (n > fix_cap) return;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1383,7 +1383,7 @@ __global__ void __launch_bounds__(256)
     if (lane == 0) {
       const float v = m + __logf(sum);
       out[(size_t)tp.x * ldo + tp.y] = v;
-      if (!(fabsf(v) <= kMaxAbsLogLike)) atomicOr(flag, 1);
+      if (!(fabsf(v) <= kMaxAbsLogLike)) ctl_or(flag, 1);
     }
   }
 }
@@ -1415,10 +1415,10 @@ __global__ void gmm_merge_parts_kernel(const SplitPdf *splits, int num_splits,
   out[(size_t)t * ldo + d.col] = v;
   if (!(fabsf(v) <= kMaxAbsLogLike)) {
     if (guard == 1) {  // differenced kernel: recompute this pair exactly
-      const int k = atomicAdd(ctl, 1);
+      const int k = ctl_add(ctl, 1);
       if (k < fix_cap) fix_list[k] = make_int2(t, d.col);
     } else {
-      atomicOr(flag, 1);
+      ctl_or(flag, 1);
     }
   }
 }
@@ -1569,7 +1569,7 @@ __global__ void __launch_bounds__(256)
   }
   const float v = mx + __logf(sum);
   out[(size_t)t * ldo + p] = v;
-  if (!(fabsf(v) <= kMaxAbsLogLike)) atomicOr(flag, 1);
+  if (!(fabsf(v) <= kMaxAbsLogLike)) ctl_or(flag, 1);
 }
 
 
@@ -2774,10 +2774,10 @@ int amlike_gmm_poll(amlike_gmm_t *g, void *stream) {
   }
   int flags[2] = {0, 0};
   AMLIKE_HIP(hipMemcpyAsync(&flags[0], g->d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-  AMLIKE_HIP(hipMemsetAsync(g->d_flag, 0, sizeof(int), st));
+  if (int crc = ClearWords(g->d_flag, 1, st)) return crc;
   if (lane_flag) {
     AMLIKE_HIP(hipMemcpyAsync(&flags[1], lane_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-    AMLIKE_HIP(hipMemsetAsync(lane_flag, 0, sizeof(int), st));
+    if (int crc = ClearWords(lane_flag, 1, st)) return crc;
   }
   AMLIKE_HIP(hipStreamSynchronize(st));
   const int flag = flags[0] | flags[1];
@@ -2926,7 +2926,7 @@ int amlike_gmm_score_submit(amlike_gmm_t *g, const float *feats, int32_t T, int3
       return AMLIKE_EINVAL;
     }
     AMLIKE_HIP(hipMemcpyAsync(s->h_flag, lane_flag, sizeof(int), hipMemcpyDeviceToHost, g->stream));
-    AMLIKE_HIP(hipMemsetAsync(lane_flag, 0, sizeof(int), g->stream));
+    if (int crc = ClearWords(lane_flag, 1, g->stream)) return crc;
   }
   AMLIKE_HIP(hipEventRecord(s->computed, g->stream));
   AMLIKE_HIP(hipStreamWaitEvent(g->copy_stream, s->computed, 0));

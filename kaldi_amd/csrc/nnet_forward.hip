@@ -385,7 +385,7 @@ __device__ __forceinline__ void store_planes(const Planes &o, size_t idx, float 
 // behind them (gmode 2) return at once when it is not.  No host round trip.
 __device__ __forceinline__ bool nnet_guard_skips(const int *flag, int gmode) {
   if (gmode == 0) return false;
-  const bool raised = __builtin_nontemporal_load(flag) != 0;
+  const bool raised = ctl_load(flag) != 0;
   return gmode == 1 ? raised : !raised;
 }
 
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256)
                               fmaxf(fmaxf(fabsf(hi.x), fabsf(hi.y)), fmaxf(fabsf(hi.z), fabsf(hi.w))));
         const bool fits = (lo.x == lo.x) & (lo.y == lo.y) & (lo.z == lo.z) & (lo.w == lo.w) &
                           (hi.x == hi.x) & (hi.y == hi.y) & (hi.z == hi.z) & (hi.w == hi.w) & (m <= 32768.0f);
-        if (!fits) atomicOr(flag, 1);
+        if (!fits) ctl_or(flag, 1);
       }
       uint4 s0, s1;
       split_f16x2_8(lo, hi, s0, s1);
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(256)
         bool fits = true;
 #pragma unroll
         for (int j = 0; j < 8; ++j) fits &= fabsf(t[j]) <= 32768.0f;  // false for NaN too
-        if (!fits) atomicOr(flag, 1);
+        if (!fits) ctl_or(flag, 1);
       }
       uint4 s0, s1;
       split_f16x2_8(lo4, hi4, s0, s1);
@@ -1703,13 +1703,15 @@ __global__ void __launch_bounds__(512, 2)
     piece_off[i] = (unsigned)(((size_t)q * wplane + (size_t)(2 * op + h) * Npad + li) * 16);
     piece_at[i] = __builtin_amdgcn_readfirstlane(piece * 64);
   }
-  auto request = [&](int seq) __attribute__((always_inline)) {
+  auto request_piece = [&](int seq, auto i_tag) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_tag)::value;
     const char *src0 = reinterpret_cast<const char *>(Wp) + (size_t)(seq % ntile) * 512;
     uint4 *dst = s_w + (seq % kRing) * kTileU4;
-#pragma unroll
-    for (int i = 0; i < kMine; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + piece_off[i]),
-                                       (__attribute__((address_space(3))) void *)(dst + piece_at[i]), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + piece_off[i]),
+                                     (__attribute__((address_space(3))) void *)(dst + piece_at[i]), 16, 0, 0);
+  };
+  auto request = [&](int seq) __attribute__((always_inline)) {
+    static_for<kMine>([&](auto i_tag) __attribute__((always_inline)) { request_piece(seq, i_tag); });
   };
 
   constexpr int NMF = KS * NPROD;  // matrix instructions per W tile
@@ -1838,7 +1840,11 @@ __global__ void __launch_bounds__(512, 2)
       // (past the end of the stream the request wraps around: harmless, and it keeps the count
       // of outstanding loads the same in every step)
 #if !(AMLIKE_ROWS_ABL & 2)  // (timing experiment: the W stream stops after its first tiles)
-      if constexpr (ks == 0) request(seq + kLead);
+      // one piece every kSpread k-steps rather than all at the head of the step, where the eight
+      // waves, fresh from the barrier, would queue 32 pieces at once
+      constexpr int kSpread = KS / kMine;
+      if constexpr (ks % kSpread == 0 && ks / kSpread < kMine)
+        request_piece(seq + kLead, std::integral_constant<int, ks / kSpread>());
 #endif
       constexpr int slot = ks == KS - 1 ? 3 : ks % 3;
 #if !(AMLIKE_ROWS_ABL & 4)
@@ -2090,16 +2096,22 @@ __global__ void __launch_bounds__(512, 2)
     piece_off[i] = (unsigned)(((size_t)q * wplane + (size_t)(2 * op + h) * Npad + li) * 16);
     piece_at[i] = __builtin_amdgcn_readfirstlane(piece * 64);
   }
-  auto request = [&](int seq) __attribute__((always_inline)) {
+  // load i of a tile's kMine + 1: W piece i, or (i == kMine) the tile's log priors
+  auto request_piece = [&](int seq, auto i_tag) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_tag)::value;
     const int tile = seq % ntile;
-    const char *src0 = reinterpret_cast<const char *>(Wp) + (size_t)tile * 512;
-    uint4 *dst = s_w + (seq % kRing) * kTileU4;
-#pragma unroll
-    for (int i = 0; i < kMine; ++i)
+    if constexpr (i < kMine) {
+      const char *src0 = reinterpret_cast<const char *>(Wp) + (size_t)tile * 512;
+      uint4 *dst = s_w + (seq % kRing) * kTileU4;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + piece_off[i]),
                                        (__attribute__((address_space(3))) void *)(dst + piece_at[i]), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(lp_src + (tile << 5) + li),
-                                     (__attribute__((address_space(3))) void *)(s_lp + (seq % kSideRing) * 64), 4, 0, 0);
+    } else {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(lp_src + (tile << 5) + li),
+                                       (__attribute__((address_space(3))) void *)(s_lp + (seq % kSideRing) * 64), 4, 0, 0);
+    }
+  };
+  auto request = [&](int seq) __attribute__((always_inline)) {
+    static_for<kMine + 1>([&](auto i_tag) __attribute__((always_inline)) { request_piece(seq, i_tag); });
   };
 
   constexpr int NMF = KS * NPROD;  // matrix instructions per W tile
@@ -2236,8 +2248,8 @@ __global__ void __launch_bounds__(512, 2)
   // One step: the matrix instructions of W tile seq into acc_new (from zero), with the vector work
   // on the previous tile (acc_old; kind 0: none, 1: sweep-1 statistics, 2: sweep-2 stores of tile
   // old_n0) between them.  SWEEP2: operands the other way round.  stores_counted: this step and
-  // the kLead - 2 before it each issue all their 16 stores, which are younger than the request
-  // waited for at the end and need not have finished.
+  // the kLead - 2 before it each issue all their 16 stores; those of this step and the one before
+  // are younger than the loads waited for at the end and need not have finished.
   auto step = [&](int seq, TileAcc &acc_new, const TileAcc &acc_old, auto sweep2_tag, auto kind_tag,
                   int old_n0, bool stores_counted) __attribute__((always_inline)) {
     constexpr bool kSweep2 = decltype(sweep2_tag)::value;
@@ -2254,7 +2266,12 @@ __global__ void __launch_bounds__(512, 2)
       else load_frag(seq + 1, std::integral_constant<int, (ks + kAhead) % KS>());
       // (past the end of the stream the request wraps around: harmless, and it keeps the count
       // of outstanding loads the same in every step)
-      if constexpr (ks == 0) request(seq + kLead);
+      // one load every kSpread k-steps rather than all at the head of the step, where the eight
+      // waves, fresh from the barrier, would queue 40 at once (measured: 1.5 % of the kernel)
+      constexpr int kSpread = (KS - 1) / kMine;
+      static_assert(kSpread >= 1 && kSpread * kMine < KS, "the tile's loads are issued within its step");
+      if constexpr (ks % kSpread == 0 && ks / kSpread <= kMine)
+        request_piece(seq + kLead, std::integral_constant<int, ks / kSpread>());
       constexpr int slot = ks == KS - 1 ? 3 : ks % 3;
       lds_hidden_wait_but<kAhead * NPL>(wf[slot][0], wf[slot][1]);  // all but the reads of the k-steps ahead
       static_for<NPROD>([&](auto j_tag) __attribute__((always_inline)) {
@@ -2290,8 +2307,10 @@ __global__ void __launch_bounds__(512, 2)
       lds_hidden_wait32(lp_cur);
       nlp = has_prior ? lp_cur * nscale : 0.0f;
     }
-    // tile seq + 2 has landed; every wave has finished reading tile seq
-    if (kKind == 2 && stores_counted) wait_vector_memory_but<(kLead - 2) * (kMine + 1) + (kLead - 1) * 16>();
+    // tile seq + 2 has landed; every wave has finished reading tile seq.  (The tile's last load was
+    // issued near the end of step seq - 2, among that step's stores: younger than it are, at least,
+    // the loads and stores of the two steps since.)
+    if (kKind == 2 && stores_counted) wait_vector_memory_but<(kLead - 2) * (kMine + 1) + (kLead - 2) * 16>();
     else wait_vector_memory_but<(kLead - 2) * (kMine + 1)>();
     barrier_only();
   };
@@ -3016,7 +3035,7 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
     if (rc != AMLIKE_OK) return rc;
   }
   const UttMap *d_maps = static_cast<const UttMap *>(n->ws_utts.ptr);
-  AMLIKE_HIP(hipMemsetAsync(n->d_flags, 0, (n->stages.size() + 1) * sizeof(int), st));
+  if (int crc = ClearWords(n->d_flags, (int)n->stages.size() + 1, st)) return crc;
 
   const float *cur = d_feats;
   int cur_ld = ld;

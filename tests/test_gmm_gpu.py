@@ -12,12 +12,21 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
+def _where(bad, got, want):
+    """Which entries are wrong: how many, over which frames and pdfs, and a few of them."""
+    rows, cols = np.nonzero(bad)
+    some = ["(%d, %d): %r for %r" % (r, c, got[r, c], want[r, c]) for r, c in list(zip(rows, cols))[:6]]
+    return ("%d of %d entries; %d frames in [%d, %d] (first %s), %d pdfs in [%d, %d] (first %s); %s"
+            % (len(rows), bad.size, len(set(rows)), rows.min(), rows.max(), sorted(set(rows))[:12], len(set(cols)),
+               cols.min(), cols.max(), sorted(set(cols))[:12], "; ".join(some)))
+
+
 def _check(m, feats, got, tol=TOL):
     gc, _ = oracle.compute_gconsts(m["weights"], m["means_invvars"], m["inv_vars"])
     want, st = oracle.gmm_compute_likes(gc, m["means_invvars"], m["inv_vars"], m["pdf_offsets"], feats)
     assert st == 0
     assert got.shape == want.shape
-    assert np.isfinite(got).all()
+    assert np.isfinite(got).all(), _where(~np.isfinite(got), got, want)
     err = np.abs(got - want).max()
     assert err < tol, "max abs diff %g" % err
     # argmax agreement, allowing exact ties within the tolerance
