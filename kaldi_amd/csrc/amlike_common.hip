@@ -88,6 +88,8 @@ class HostCopyPool {
       CopyRows(dst, dpitch, src, spitch, width, 0, rows);
       return;
     }
+    // one split copy at a time (callers on different devices share the pool and its counter)
+    std::lock_guard<std::mutex> one_call(call_mu_);
     {
       std::unique_lock<std::mutex> lock(mu_);
       pending_ = parts - 1;
@@ -140,7 +142,7 @@ class HostCopyPool {
   }
   std::vector<std::thread> workers_;
   std::vector<std::function<void()>> tasks_;
-  std::mutex mu_;
+  std::mutex mu_, call_mu_;
   std::condition_variable cv_, done_;
   int pending_ = 0;
   bool stop_ = false;

@@ -2263,7 +2263,11 @@ static int LaneFor(amlike_gmm *g, hipStream_t stream, StreamLane **out) {
     lane->stream = stream;
     if (!lane->d_ctl) {
       AMLIKE_HIP(hipMalloc(&lane->d_ctl, 2 * kCtlBlockBytes));
-      AMLIKE_HIP(hipMemset(lane->d_ctl, 0, 2 * kCtlBlockBytes));
+      // Zeroed on the lane's own stream, ahead of its first call's kernels.  (A hipMemset runs on the
+      // null stream and returns before it has run; the caller's stream need not wait for that
+      // stream, and the fill then landed, now and then, in the middle of the first call: a raised
+      // flag or an overflow count wiped out.)
+      if (int crc = ClearWords(lane->d_ctl, (int)(2 * kCtlBlockBytes / sizeof(int)), stream)) return crc;
     }
   }
   lane->last_use = ++g->lane_clock;
@@ -2588,7 +2592,8 @@ int amlike_gmm_create(const float *gconsts, const float *means_invvars, const fl
   }
   if (rc == AMLIKE_OK) {
     hipError_t e = hipMalloc(&g->d_flag, sizeof(int));
-    if (e == hipSuccess) e = hipMemset(g->d_flag, 0, sizeof(int));
+    const int zero = 0;  // (a blocking copy: finished when it returns, whatever stream comes next)
+    if (e == hipSuccess) e = hipMemcpy(g->d_flag, &zero, sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
       SetError("amlike_gmm_create: %s", hipGetErrorString(e));

@@ -899,8 +899,9 @@ __global__ void __launch_bounds__(256)
 template <int RB>
 __global__ void __launch_bounds__(256)
     nnet_normalize_planes_kernel(const float *__restrict__ in, int ld_in, int dim, int rows,
-                                 Planes out, int one_col) {
+                                 Planes out, int one_col, const int *flag, int gmode) {
   constexpr int NQ = 256 / RB;  // threads per row
+  if (nnet_guard_skips(flag, gmode)) return;
   extern __shared__ float s_norm[];
   const int dimp = dim | 1;
   float *s_x = s_norm;              // [RB][dimp]
@@ -1656,18 +1657,27 @@ struct RowJobs {
 
 __host__ __device__ constexpr int PnormRowsRing(int KS) {
   const int tile = 2 * 2 * KS * 32 * 16;
-  return 160 * 1024 / tile >= 6 ? 5 : 160 * 1024 / tile - 1;
+  return 160 * 1024 / tile >= 6 ? 5 : 160 * 1024 / tile >= 5 ? 4 : 160 * 1024 / tile;
 }
 
-template <int KS>
-__global__ void __launch_bounds__(512, 2)
+// NW = 8: two waves per SIMD, 256 rows per job (k of 13 steps: the X fragments of a wave take 104
+// registers).  NW = 4: one wave per SIMD with the whole register file, 128 rows per job, for wider
+// inputs (k of 23 steps, 184 registers of fragments: the first hidden layer behind the splice);
+// the wave then runs two accumulator chains, there being no partner to fill the gap a dependent
+// matrix instruction leaves, and the W ring holds three tiles.
+// flag / gmode: as nnet_guard_skips (layers whose input range is decided on the device).
+template <int KS, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1)
     nnet_pnorm_rows_kernel(const uint4 *__restrict__ Xp, size_t xplane, const uint4 *__restrict__ Wp,
                            size_t wplane, int Npad, float *__restrict__ Y, int ldy, int M, int G,
-                           RowJobs jobs, Planes nout, int one_col) {
-  constexpr int NPL = 2, NPROD = 3, NW = 8;
+                           RowJobs jobs, Planes nout, int one_col, const int *flag, int gmode) {
+  constexpr int NPL = 2, NPROD = 3;
+  constexpr int kJobRows = NW * 32;
+  constexpr bool kOneChain = AMLIKE_ROWS_ONECHAIN && NW == 8;
   constexpr int kTileU4 = NPL * 2 * KS * 32;  // uint4 per staged W tile: [plane][octet][32 units]
   constexpr int kRing = PnormRowsRing(KS), kLead = kRing - 1;  // tile seq + kLead is requested in step seq
-  static_assert(kRing >= 4, "the W ring needs four tiles");
+  static_assert(kRing >= 3, "the W ring needs three tiles");
+  if (nnet_guard_skips(flag, gmode)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
   uint4 *s_w = reinterpret_cast<uint4 *>(smem_r);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1675,10 +1685,10 @@ __global__ void __launch_bounds__(512, 2)
   int row0, nrows;
   const int b = blockIdx.x;
   if (b < jobs.nbig) {
-    row0 = b * 256;
-    nrows = 256;
+    row0 = b * kJobRows;
+    nrows = kJobRows;
   } else {
-    row0 = jobs.nbig * 256 + (b - jobs.nbig) * jobs.small;
+    row0 = jobs.nbig * kJobRows + (b - jobs.nbig) * jobs.small;
     nrows = min(jobs.small, M - row0);
   }
   if (nrows <= 0) return;
@@ -1742,11 +1752,8 @@ __global__ void __launch_bounds__(512, 2)
   // the vector work on value r of a finished tile
   auto square_unit = [&](const TileAcc &acc, auto r_tag) __attribute__((always_inline)) {
     constexpr int r = decltype(r_tag)::value;
-#if AMLIKE_ROWS_ONECHAIN
-    const float v = acc.x[r];
-#else
-    const float v = acc.x[r] + acc.y[r];
-#endif
+    float v = acc.x[r];
+    if constexpr (!kOneChain) v += acc.y[r];
     ss[r & 7] = fmaf(v, v, ss[r & 7]);
     pin_order(ss[r & 7]);
   };
@@ -1789,21 +1796,25 @@ __global__ void __launch_bounds__(512, 2)
   };
 
   constexpr int kAhead = 2;
-  static_assert(KS % 3 == 1, "the register slots below assume KS = 3 n + 1");
+  // Register slots of the W fragments: k-step ks uses slot ks % 3, except that the last KS % 3
+  // k-steps of a tile use slots 3 and 4 -- while they run, the first k-steps of the next tile
+  // are already being read into slots 0 and 1.
+  constexpr int kTailSteps = KS % 3, kSlots = 3 + kTailSteps;
+  auto slot_of = [](int ks) constexpr { return ks >= KS - kTailSteps ? 3 + (ks - (KS - kTailSteps)) : ks % 3; };
   // Fragments of W, read from LDS kAhead k-steps before their use, as reads the compiler does not
   // see, with counted waits: left to the compiler, every third k-step waited for ALL reads in
   // flight, the ones just issued included.  Past the end of the stream the reads go on (to a
   // ring slot that holds some older tile; the values are not used): the count of reads in
   // flight is the same at every k-step.
-  f32x4 wf[4][NPL];
+  f32x4 wf[kSlots][NPL];
 #pragma unroll
-  for (int sl = 0; sl < 4; ++sl)
+  for (int sl = 0; sl < kSlots; ++sl)
 #pragma unroll
     for (int q = 0; q < NPL; ++q) wf[sl][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   const unsigned s_w_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) uint4 *)s_w +
                             (unsigned)(h * 32 + li) * 16u;
   auto load_frag = [&](int seq, auto ks_tag) __attribute__((always_inline)) {  // k-step ks of tile seq
-    constexpr int ks = decltype(ks_tag)::value, slot = ks == KS - 1 ? 3 : ks % 3;
+    constexpr int ks = decltype(ks_tag)::value, slot = slot_of(ks);
     const unsigned at = s_w_addr + (unsigned)(seq % kRing) * (unsigned)(kTileU4 * 16);
     static_for<NPL>([&](auto q_tag) __attribute__((always_inline)) {
       constexpr int q = decltype(q_tag)::value;
@@ -1846,7 +1857,7 @@ __global__ void __launch_bounds__(512, 2)
       if constexpr (ks % kSpread == 0 && ks / kSpread < kMine)
         request_piece(seq + kLead, std::integral_constant<int, ks / kSpread>());
 #endif
-      constexpr int slot = ks == KS - 1 ? 3 : ks % 3;
+      constexpr int slot = slot_of(ks);
 #if !(AMLIKE_ROWS_ABL & 4)
       lds_hidden_wait_but<kAhead * NPL>(wf[slot][0], wf[slot][1]);  // all but the reads of the k-steps ahead
 #endif
@@ -1854,15 +1865,15 @@ __global__ void __launch_bounds__(512, 2)
         // order within a k-step: cross product, high parts, cross product (y, x, y)
         constexpr int j = decltype(j_tag)::value, mi = ks * NPROD + j;
         // the fragments of X live in the accumulation registers, the accumulators in the ordinary ones
-#if AMLIKE_ROWS_ONECHAIN  // (A/B aid: all three products in one chain)
-        if constexpr (j == 0) mfma_f16_asm_vacc<ks == 0>(acc_new.x, wf[slot][1], xf[ks][0]);
-        else if constexpr (j == 1) mfma_f16_asm_vacc<false>(acc_new.x, wf[slot][0], xf[ks][1]);
-        else mfma_f16_asm_vacc<false>(acc_new.x, wf[slot][0], xf[ks][0]);
-#else
-        if constexpr (j == 0) mfma_f16_asm_vacc<ks == 0>(acc_new.y, wf[slot][1], xf[ks][0]);
-        else if constexpr (j == 1) mfma_f16_asm_vacc<ks == 0>(acc_new.x, wf[slot][0], xf[ks][0]);
-        else mfma_f16_asm_vacc<false>(acc_new.y, wf[slot][0], xf[ks][1]);
-#endif
+        if constexpr (kOneChain) {  // all three products in one chain
+          if constexpr (j == 0) mfma_f16_asm_vacc<ks == 0>(acc_new.x, wf[slot][1], xf[ks][0]);
+          else if constexpr (j == 1) mfma_f16_asm_vacc<false>(acc_new.x, wf[slot][0], xf[ks][1]);
+          else mfma_f16_asm_vacc<false>(acc_new.x, wf[slot][0], xf[ks][0]);
+        } else {  // x: the high parts' products, y: the two cross products
+          if constexpr (j == 0) mfma_f16_asm_vacc<ks == 0>(acc_new.y, wf[slot][1], xf[ks][0]);
+          else if constexpr (j == 1) mfma_f16_asm_vacc<ks == 0>(acc_new.x, wf[slot][0], xf[ks][0]);
+          else mfma_f16_asm_vacc<false>(acc_new.y, wf[slot][0], xf[ks][1]);
+        }
         // The previous tile's values are read from the fourth matrix instruction of the step on: by
         // then the last matrix instruction of the previous step has long delivered its result.
         if constexpr (kWork && !(AMLIKE_ROWS_ABL & 1) && mi >= kSkip) {  // (bit 0, timing experiment: no vector work)
@@ -2576,6 +2587,7 @@ struct amlike_nnet {
   bool no_direct_planes = false;  // AMLIKE_NNET_NO_DIRECT_PLANES: no stage writes its consumer's operand planes
   int rows_norm = 1;  // AMLIKE_NNET_ROWS_NORM=0: the normalisation behind the row-stationary kernel stays a kernel of its own (A/B aid)
   int out_rows = 1;  // AMLIKE_NNET_OUT_ROWS=0: never the 8-wave output-layer + softmax kernel (A/B aid)
+  int first_rows = 1;  // AMLIKE_NNET_FIRST_ROWS=0: the wide-input (k = 368) layer stays on nnet_gemm_pnorm_kernel (A/B aid)
   int collapse = 1;  // AMLIKE_NNET_COLLAPSE=0: an affine stage right behind another stays a stage of its own (A/B aid)
   float *d_log_priors = nullptr;
   hipStream_t stream = nullptr;
@@ -2724,27 +2736,40 @@ static std::vector<uint16_t> BuildPnormRowsWeights(const std::vector<float> &w, 
 }
 
 static int LaunchPnormRows(const Stage &s, const uint4 *xp, size_t xplane, float *y, int ldy, int rows, int G,
-                           hipStream_t st, Planes nout = Planes{nullptr, 0, 0}, int one_col = -1) {
-  // Jobs: as many full rounds of 256-row jobs as the CUs take evenly, then the rest in equal
-  // shares (multiples of 32 rows) so that the last round is short everywhere.
+                           hipStream_t st, Planes nout = Planes{nullptr, 0, 0}, int one_col = -1,
+                           const int *flag = nullptr, int gmode = 0) {
+  // Jobs: as many full rounds of whole jobs (256 rows, or 128 for the wide-input form) as the CUs
+  // take evenly, then the rest in equal shares (multiples of 32 rows) so that the last round is
+  // short everywhere.
+  const int KS = s.Kpn / 16;
+  const int job_rows = KS == 13 ? 256 : 128;
   const int cus = std::max(1, NumComputeUnits());
   RowJobs jobs;
-  jobs.nbig = (rows / 256 / cus) * cus;
-  const int rest = rows - jobs.nbig * 256;
-  jobs.small = 256;
+  jobs.nbig = (rows / job_rows / cus) * cus;
+  const int rest = rows - jobs.nbig * job_rows;
+  jobs.small = job_rows;
   int nsmall = 0;
   if (rest > 0) {
-    jobs.small = std::min(256, RoundUp((rest + cus - 1) / cus, 32));
+    jobs.small = std::min(job_rows, RoundUp((rest + cus - 1) / cus, 32));
     nsmall = (rest + jobs.small - 1) / jobs.small;
   }
   const int grid = jobs.nbig + nsmall;
-  const int KS = s.Kpn / 16;
   const size_t wplane = (size_t)s.Npad * (s.Kpn / 8);
   const size_t smem = (size_t)PnormRowsRing(KS) * 2 * 2 * KS * 32 * sizeof(uint4);
-  AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nnet_pnorm_rows_kernel<13>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL((nnet_pnorm_rows_kernel<13>), dim3(grid), dim3(512), smem, st, xp, xplane, s.d_wpr, wplane,
-                     s.Npad, y, ldy, rows, G, jobs, nout, one_col);
+#define AMLIKE_ROWS_LAUNCH(KSV, NWV)                                                                       \
+  do {                                                                                                     \
+    AMLIKE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nnet_pnorm_rows_kernel<KSV, NWV>),       \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                \
+    hipLaunchKernelGGL((nnet_pnorm_rows_kernel<KSV, NWV>), dim3(grid), dim3(64 * NWV), smem, st, xp,       \
+                       xplane, s.d_wpr, wplane, s.Npad, y, ldy, rows, G, jobs, nout, one_col, flag, gmode); \
+  } while (0)
+  if (KS == 13) AMLIKE_ROWS_LAUNCH(13, 8);
+  else if (KS == 23) AMLIKE_ROWS_LAUNCH(23, 4);
+  else {
+    SetError("nnet2 forward: no row-stationary p-norm kernel for k = %d", s.Kpn);
+    return AMLIKE_EINVAL;
+  }
+#undef AMLIKE_ROWS_LAUNCH
   AMLIKE_HIP(hipGetLastError());
 #ifdef AMLIKE_ROWS_STAMPS
   {
@@ -3188,7 +3213,49 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
       if (s.f16 == 2) {
         split(1, pbase, 1);
         AMLIKE_HIP(hipGetLastError());
-        fused(1, pbase, s.d_wpn, 1);
+        const Stage *nx1 = (norm && si + 2 < ns) ? &n->stages[si + 2] : nullptr;
+        if (s.d_wpr && cur_rows >= 64 && n->first_rows && nx1 && nx1->kind == AMLIKE_AFFINE && nx1->f16 == 1 &&
+            nx1->in_dim == G && G <= 240 && n->rows_norm && !n->gemm_f32 && !n->gemm_inline_split &&
+            !n->no_direct_planes) {
+          // Rows stationary, one wave per SIMD, normalising its rows and writing the next stage's
+          // planes (into the other planes buffer) when the fp16x2 attempt stands; otherwise the
+          // bf16x3 twin on the older kernel, and the normalisation into the same planes by a kernel
+          // of its own that runs only then.
+          const bool nx_fused = nx1->fuse_gs && si + 3 < ns;
+          const int ckp = nx_fused ? nx1->Kpn : nx1->Kp;
+          const size_t cstride = (size_t)cur_rows * ckp;
+          DeviceBuffer *other = wsp == &n->ws_planes ? &n->ws_planes_b : &n->ws_planes;
+          rc = other->Reserve(3 * cstride * sizeof(unsigned short));
+          if (rc != AMLIKE_OK) return rc;
+          const Planes cp{static_cast<unsigned short *>(other->ptr), cstride, ckp};
+          const int cons_one = (nx_fused || nx1->d_wob) ? nx1->in_dim : -1;
+          rc = LaunchPnormRows(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, pdst, pld, (int)cur_rows, G, st,
+                               cp, cons_one, flag, 1);
+          if (rc != AMLIKE_OK) return rc;
+          split(0, pbase + 2 * pstride, 2);
+          AMLIKE_HIP(hipGetLastError());
+          fused(0, pbase + 2 * pstride, s.d_wpn_safe, 2);
+          AMLIKE_HIP(hipGetLastError());
+          hipLaunchKernelGGL(nnet_normalize_planes_kernel<64>, dim3((unsigned)((cur_rows + 63) / 64)), dim3(256),
+                             ((size_t)64 * (G | 1) + 256) * sizeof(float), st, pdst, pld, G, (int)cur_rows, cp,
+                             cons_one, flag, 2);
+          AMLIKE_HIP(hipGetLastError());
+          wsp = other;
+          planes_ready = 1;
+          cur = nullptr;  // no fp32 copy of the normalised rows exists
+          cur_ld = RoundUp(G, 16);
+          which ^= 1;
+          ++si;  // the p-norm stage is done
+          continue;
+        }
+        if (s.d_wpr && cur_rows >= 64 && n->first_rows) {
+          // rows stationary, one wave per SIMD (the fp16x2 attempt; the bf16x3 twin keeps the older kernel)
+          rc = LaunchPnormRows(s, reinterpret_cast<const uint4 *>(pbase), pstride / 8, pdst, pld, (int)cur_rows, G, st,
+                               Planes{nullptr, 0, 0}, -1, flag, 1);
+          if (rc != AMLIKE_OK) return rc;
+        } else {
+          fused(1, pbase, s.d_wpn, 1);
+        }
         AMLIKE_HIP(hipGetLastError());
         split(0, pbase + 2 * pstride, 2);
         AMLIKE_HIP(hipGetLastError());
@@ -3250,10 +3317,10 @@ static int Forward(amlike_nnet *n, const float *d_feats, int ld, const int32_t *
         const size_t nsmem = ((size_t)rb * (G | 1) + 256) * sizeof(float);
         if (rb == 64)
           hipLaunchKernelGGL(nnet_normalize_planes_kernel<64>, dim3((unsigned)((cur_rows + 63) / 64)), dim3(256),
-                             nsmem, st, pdst, pld, G, (int)cur_rows, cp, cons_one);
+                             nsmem, st, pdst, pld, G, (int)cur_rows, cp, cons_one, nullptr, 0);
         else
           hipLaunchKernelGGL(nnet_normalize_planes_kernel<32>, dim3((unsigned)((cur_rows + 31) / 32)), dim3(256),
-                             nsmem, st, pdst, pld, G, (int)cur_rows, cp, cons_one);
+                             nsmem, st, pdst, pld, G, (int)cur_rows, cp, cons_one, nullptr, 0);
         AMLIKE_HIP(hipGetLastError());
         planes_ready = 1;
         fin = nullptr;  // no fp32 copy exists
@@ -3471,6 +3538,7 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
   if (const char *e = getenv("AMLIKE_NNET_PNORM_ROWS")) n->pnorm_rows = e[0] != '0';
   if (const char *e = getenv("AMLIKE_NNET_COLLAPSE")) n->collapse = e[0] != '0';
   if (const char *e = getenv("AMLIKE_NNET_OUT_ROWS")) n->out_rows = e[0] != '0';
+  if (const char *e = getenv("AMLIKE_NNET_FIRST_ROWS")) n->first_rows = e[0] != '0';
   if (const char *e = getenv("AMLIKE_NNET_ROWS_NORM")) n->rows_norm = e[0] != '0';
   if (const char *e = getenv("AMLIKE_NNET_OUT_CUS")) n->out_cus = std::max(1, atoi(e));
   n->out_no_stagger = getenv("AMLIKE_NNET_OUT_NO_STAGGER") != nullptr;
@@ -3657,7 +3725,8 @@ int amlike_nnet_create(const amlike_component_t *comps, int32_t num, const float
             }
             // the row-stationary kernel's image: fp16x2 operands behind a NormalizeComponent,
             // groups of 10, k of 13 steps with the bias column (AMLIKE_NNET_PNORM_ROWS=0: A/B aid)
-            if (e == hipSuccess && a.f16 == 1 && gs == 10 && a.Kpn == 208 && n->pnorm_rows) {
+            if (e == hipSuccess && gs == 10 && n->pnorm_rows &&
+                ((a.f16 == 1 && a.Kpn == 208) || (a.f16 == 2 && a.Kpn == 368))) {
               int kpn2 = 0, npad2 = 0;
               std::vector<uint16_t> rows_img = BuildPnormRowsWeights(a.h_w, a.Kp, a.h_b, a.out_dim, a.in_dim,
                                                                      &kpn2, &npad2);

@@ -46,12 +46,15 @@ def regs(operand):
     return {int(m.group(1))} if m else set()
 
 
-@pytest.mark.parametrize("kernel,steps,parked", [("nnet_pnorm_rows_kernel", 3, 8), ("nnet_out_rows_kernel", 7, 32)])
+@pytest.mark.parametrize("kernel,steps,parked", [("nnet_pnorm_rows_kernelILi13ELi8E", 3, 8),
+                                                 ("nnet_pnorm_rows_kernelILi23ELi4E", 5, 8),
+                                                 ("nnet_out_rows_kernel", 7, 32)])
 def test_nothing_touches_a_matrix_instructions_registers_right_behind_it(kernel, steps, parked):
     """For every matrix instruction and the six instructions behind it: no vector instruction reads
     or writes its result registers, and none writes its operands' registers (an LDS read may name
-    them as its destination: its data arrives long after).  `steps`: instances of the 39-instruction
-    step the kernel is known to hold at least; `parked`: moves to and from the accumulation registers
+    them as its destination: its data arrives long after).  `kernel`: a part of the mangled name
+    (the template arguments included where several instantiations exist); `steps`: the kernel is
+    known to hold at least 39 x steps matrix instructions; `parked`: moves to and from the accumulation registers
     tolerated up to the last matrix instruction (values parked across a loop)."""
     code = disassemble_kernel(kernel)
     assert sum(l.startswith("v_mfma") for l in code) >= 39 * steps
