@@ -64,10 +64,10 @@ F16X2_PRODUCTS = 3
 # the chip sustains under the matrix pipe depends on the switching activity of the data)
 MEASURED_F16_MFMA_TFLOPS = 2419.0
 MEASURED_F16_MFMA_TFLOPS_RANDOM = 1700.0
-# (profiles/r3_z_*_pmc_summary.txt: the current kernel; the counters are in KiB -- the nnet2 output
+# (profiles/r3_zz_*_pmc_summary.txt: the current kernel; the counters are in KiB -- the nnet2 output
 # kernel's WRITE_SIZE x 1024 equals its [T x 8600] x 4 bytes exactly)
-PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 2444940.0, 9196480.0
-PMC_SOURCE = "profiles/r3_z_gmm_diff_pmc_summary.txt"
+PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 2450810.0, 9239440.0
+PMC_SOURCE = "profiles/r3_zz_gmm_diff_pmc_summary.txt"
 
 
 def _cpu_model():

@@ -15,8 +15,8 @@ HBM_PEAK_TBS = 8.0
 # HBM traffic of one forward pass of this workload (256 utterances, 218 541 frames), from rocprofv3
 # --pmc passes (FETCH_SIZE, WRITE_SIZE in KB summed over the pass's kernels; FETCH_SIZE x2 as for the
 # GMM kernel): constants, not re-measured by a bench run.
-PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 1622271.0, 9091937.0
-PMC_SOURCE = "profiles/r3_z_nnet_pmc_summary.txt"
+PMC_FRAMES, PMC_FETCH_KB, PMC_WRITE_KB = 218541, 1575653.0, 9095452.0
+PMC_SOURCE = "profiles/r3_zz_nnet_pmc_summary.txt"
 
 
 def run(dev, stream, world, utts_per_gpu=40, steps=10, warmup=2, rank=0):
