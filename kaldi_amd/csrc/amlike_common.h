@@ -39,10 +39,10 @@ int SetupNoAllocScratch(int device);
 
 // Control words in device memory (overflow counts, "out of range" and "not finite" flags): a
 // kernel raises them, later kernels of the same call decide by them what to run, the host reads
-// them back.  The chip's compute dies each have an L2 of their own, and an ordinary load may be
-// served from a die's copy of the line taken before another die's atomic changed the word (seen
-// as, rarely, a repair pass that found an empty list, or a flag the host never saw).  These
-// accesses therefore go at system scope, past the L2s, for readers and writers alike.
+// them back.  The chip's compute dies each have an L2 of their own, agent-scope atomics carry no
+// cache-scope bit, and an ordinary load may be served from a die's copy of the line taken before
+// another die's atomic changed the word.  These few accesses therefore go at system scope, past
+// the L2s, for readers and writers alike.
 #if defined(__HIPCC__)
 __device__ __forceinline__ int ctl_load(const int *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
